@@ -1,0 +1,164 @@
+"""ctypes binding of include/envpool_amd.h — the C ABI exactly as a foreign caller sees it.
+
+Used by the parity tests and bench.py so that they exercise the drop-in boundary itself,
+not a Python convenience layer.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._loader import load_library
+
+EP_OK, EP_ERR_INVALID, EP_ERR_HIP, EP_ERR_NO_DEVICE = 0, 1, 2, 3
+EP_ERR_WOULD_BLOCK, EP_ERR_RING_FULL, EP_ERR_ACTION_CHECK, EP_ERR_TOO_LARGE = 4, 5, 6, 7
+EP_MEM_HOST, EP_MEM_DEVICE = 0, 1
+EP_I32, EP_F32, EP_F64, EP_BOOL, EP_U8, EP_CONTAINER_I32 = range(6)
+EP_MAX_KEYS, EP_MAX_NDIM = 20, 4
+
+_NP = {EP_I32: np.int32, EP_F32: np.float32, EP_F64: np.float64, EP_BOOL: np.bool_, EP_U8: np.uint8}
+
+
+class DummyConfig(C.Structure):
+  _fields_ = [(k, C.c_int32) for k in (
+    "num_envs", "batch_size", "num_threads", "max_num_players", "thread_affinity_offset", "seed",
+    "max_episode_steps", "state_num", "action_num", "device_id", "env_id_offset", "ring_depth")]
+
+
+class Array(C.Structure):
+  _fields_ = [("data", C.c_void_p), ("shape", C.c_int64 * EP_MAX_NDIM), ("ndim", C.c_int32),
+              ("dtype", C.c_int32)]
+
+
+class Batch(C.Structure):
+  _fields_ = [("num_keys", C.c_int32), ("mem", C.c_int32), ("num_rows", C.c_int32),
+              ("num_player_rows", C.c_int32), ("seq", C.c_uint64), ("owner", C.c_void_p),
+              ("arrays", Array * EP_MAX_KEYS)]
+
+
+SYMBOLS = [
+  "ep_dummy_pool_create", "ep_pool_destroy", "ep_pool_reset", "ep_pool_send", "ep_pool_recv",
+  "ep_batch_release", "ep_pool_rollout", "ep_pool_sync", "ep_pool_episode_stats",
+  "ep_pool_checkpoint_bytes", "ep_pool_checkpoint_save", "ep_pool_checkpoint_restore",
+  "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
+  "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
+  "ep_last_error", "ep_version",
+]
+
+_bound = None
+
+
+def lib():
+  global _bound
+  if _bound is None:
+    L = load_library()
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ep_dummy_pool_create.argtypes = [C.POINTER(DummyConfig), C.POINTER(vp)]
+    L.ep_pool_destroy.argtypes = [vp]
+    L.ep_pool_reset.argtypes = [vp, vp, i32, i32]
+    L.ep_pool_send.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64), i32]
+    L.ep_pool_recv.argtypes = [vp, i32, C.POINTER(Batch)]
+    L.ep_batch_release.argtypes = [C.POINTER(Batch)]
+    L.ep_pool_rollout.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.ep_pool_sync.argtypes = [vp]
+    L.ep_pool_episode_stats.argtypes = [vp, vp, vp, vp, i32]
+    L.ep_pool_checkpoint_bytes.argtypes = [vp]
+    L.ep_pool_checkpoint_bytes.restype = i64
+    L.ep_pool_checkpoint_save.argtypes = [vp, vp]
+    L.ep_pool_checkpoint_restore.argtypes = [vp, vp]
+    for f in ("ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync"):
+      getattr(L, f).argtypes = [vp]
+    L.ep_pool_stream.argtypes = [vp]
+    L.ep_pool_stream.restype = vp
+    L.ep_pool_set_timing.argtypes = [vp, i32]
+    L.ep_pool_kernel_time_us.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), i32]
+    L.ep_last_error.restype = C.c_char_p
+    L.ep_version.restype = C.c_char_p
+    _bound = L
+  return _bound
+
+
+class EpError(RuntimeError):
+  def __init__(self, code, msg):
+    super().__init__(f"[ep_status {code}] {msg}")
+    self.code = code
+
+
+def _check(rc, allow=()):
+  if rc != EP_OK and rc not in allow:
+    raise EpError(rc, lib().ep_last_error().decode())
+  return rc
+
+
+def batch_to_numpy(b: Batch):
+  """Host batch -> list of numpy copies in _state_keys order (obs:dyn -> None)."""
+  out = []
+  for k in range(b.num_keys):
+    a = b.arrays[k]
+    if a.dtype == EP_CONTAINER_I32:
+      out.append(None)
+      continue
+    shape = tuple(a.shape[i] for i in range(a.ndim))
+    n = int(np.prod(shape))
+    dt = np.dtype(_NP[a.dtype])
+    if n == 0:
+      out.append(np.zeros(shape, dt))
+    else:
+      buf = (C.c_char * (n * dt.itemsize)).from_address(a.data)
+      out.append(np.frombuffer(buf, dtype=dt).reshape(shape).copy())
+  return out
+
+
+class DummyPoolC:
+  """Thin object wrapper over the raw C entry points (host-memory flavour)."""
+
+  def __init__(self, **kw):
+    cfg = DummyConfig(num_envs=1, batch_size=0, num_threads=0, max_num_players=1,
+                      thread_affinity_offset=-1, seed=42, max_episode_steps=2**31 - 1, state_num=10,
+                      action_num=6, device_id=0, env_id_offset=0, ring_depth=0)
+    for k, v in kw.items():
+      setattr(cfg, k, v)
+    self.cfg = cfg
+    self._L = lib()
+    h = C.c_void_p()
+    _check(self._L.ep_dummy_pool_create(C.byref(cfg), C.byref(h)))
+    self._h = h
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._L.ep_pool_destroy(self._h)
+      self._h = None
+
+  __del__ = close
+
+  @property
+  def handle(self):
+    return self._h
+
+  def _reset(self, env_ids):
+    ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+    _check(self._L.ep_pool_reset(self._h, ids.ctypes.data, ids.shape[0], EP_MEM_HOST))
+
+  def _send(self, action):
+    arrs = [np.ascontiguousarray(action[0], np.int32), np.ascontiguousarray(action[1], np.int32),
+            np.ascontiguousarray(action[2], np.float64), np.ascontiguousarray(action[3], np.int32),
+            np.ascontiguousarray(action[4], np.int32)]
+    ptrs = (C.c_void_p * 5)(*[a.ctypes.data for a in arrs])
+    dims = (C.c_int64 * 5)(*[a.shape[0] for a in arrs])
+    _check(self._L.ep_pool_send(self._h, 5, ptrs, dims, EP_MEM_HOST))
+
+  def _recv(self, allow=()):
+    b = Batch()
+    rc = _check(self._L.ep_pool_recv(self._h, EP_MEM_HOST, C.byref(b)), allow=allow)
+    out = batch_to_numpy(b)
+    self._L.ep_batch_release(C.byref(b))
+    self.last_status = rc
+    return out
+
+  def sync(self):
+    _check(self._L.ep_pool_sync(self._h))
+
+  def episode_stats(self):
+    n = self._L.ep_pool_num_envs(self._h)
+    r, l, c = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    _check(self._L.ep_pool_episode_stats(self._h, r.ctypes.data, l.ctypes.data, c.ctypes.data, EP_MEM_HOST))
+    return r, l, c

@@ -1,0 +1,816 @@
+// pool.hip — device-resident replacement of envpool2/core's AsyncEnvPool /
+// ActionBufferQueue / StateBufferQueue for Dummy-v0, behind the C ABI of
+// include/envpool_amd.h.
+//
+// The reference's moving parts and what stands in for them here:
+//   ActionBufferQueue (action_buffer_queue.h:35-85)   -> the HIP stream: a send IS a kernel
+//       launch, FIFO by construction; a pinned staging ring + copy stream carries host actions.
+//   worker threads (async_envpool.h:116-129)          -> one GPU thread per env-step.
+//   StateBufferQueue ring (state_buffer_queue.h:32-151)-> `ring_depth` slots in ONE HBM
+//       allocation; the host mirrors alloc_count_/done_ptr_ and per-buffer offsets, so row
+//       assignment costs no device atomics (every slice yields exactly one shared row).
+//   background zero-fill thread (:82-95)              -> gone; kernels write whole rows.
+//   semaphores / StateBuffer::Wait (state_buffer.h:135-157) -> one hipEvent per slot.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/envpool_amd.h"
+#include "dummy_kernels.hpp"
+#include "dummy_mp_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(EP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                              \
+  } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+// A pool of pinned host blocks that outlives the ep_pool if numpy still holds a batch
+// (the reference hands out buffers that are never reused, py_envpool.h:42-46).
+struct HostBlocks {
+  std::mutex mu;
+  std::vector<void*> free_list;
+  size_t bytes = 0;
+  bool alive = true;
+};
+struct HostBlockOwner {
+  std::shared_ptr<HostBlocks> home;
+  void* ptr;
+};
+
+struct SlotHost {
+  uint64_t alloc_count = 0;  // StateBuffer::alloc_count_
+  uint32_t shared_off = 0;   // low half of StateBuffer::offsets_
+  std::vector<std::pair<int64_t, int64_t>> written;  // shared rows written, [a,b)
+  hipEvent_t ready = nullptr;
+  bool has_work = false;
+};
+
+}  // namespace
+
+struct ep_pool {
+  ep_dummy_config cfg{};
+  int N = 0, B = 0, P = 0, S = 0, Q = 0;
+  bool is_sync = false;
+  int device = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  // device state
+  epk::EnvRec* d_env = nullptr;
+  epk::StatPtrs stats{};
+  char* d_ring = nullptr;
+  size_t slot_stride = 0;
+  size_t key_off[11]{};
+  size_t key_rowbytes[11]{};
+  bool key_is_player[11]{};
+  // multi-player scratch
+  int32_t* d_mp_counts = nullptr;   // [N] rows of players.env_id per env in the current send
+  int32_t* d_mp_np = nullptr;       // [cap] players per item
+  int32_t* d_mp_off = nullptr;      // [cap] exclusive scan
+  void* d_mp_items = nullptr;       // [cap] epk::MpItem
+  int32_t* d_mp_base = nullptr;     // [1] player rows already in the slot before this segment
+  uint32_t* d_slot_players = nullptr;  // [Q] player_offset of each slot (device counter)
+  uint32_t* h_slot_players = nullptr;  // pinned mirror
+  // error words (host-mapped)
+  epk::ErrWords* h_err = nullptr;  // [Q]
+  epk::ErrWords* d_err = nullptr;  // device alias of h_err
+  // action staging for host sends
+  int A = 0;
+  size_t stage_bytes = 0;
+  char* h_stage = nullptr;
+  char* d_stage = nullptr;
+  std::vector<hipEvent_t> stage_free;  // recorded on `stream` after the consuming kernel
+  std::vector<hipEvent_t> stage_copied;
+  uint64_t stage_idx = 0;
+  // host mirror of the queue counters
+  uint64_t alloc_count = 0, done_ptr = 0;  // StateBufferQueue::alloc_count_/done_ptr_ (in rows / batches)
+  int64_t stepping_env_num = 0;            // async_envpool.h:49
+  uint64_t recv_seq = 0;
+  std::vector<SlotHost> slots;
+  std::mutex mu;
+  std::shared_ptr<HostBlocks> blocks;
+  // kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+  std::vector<hipEvent_t> ev_pool;
+  double timed_total_us = 0;
+  int64_t timed_launches = 0;
+};
+
+namespace epk_mp {
+int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
+               int np_rows, bool force_reset);
+}
+
+namespace {
+
+// state-key index (in _state_keys order, 12 keys) -> slot key index (obs:dyn has no array)
+const int kStateToSlot[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, -1, 9, 10};
+const int kSlotDtype[11] = {EP_I32, EP_I32, EP_I32, EP_BOOL, EP_F32, EP_F32,
+                            EP_I32, EP_BOOL, EP_I32, EP_BOOL, EP_I32};
+const int kSlotElem[11] = {4, 4, 4, 1, 4, 4, 4, 1, 4, 1, 4};
+
+int set_device(ep_pool* p) {
+  HIP_TRY(hipSetDevice(p->device));
+  return EP_OK;
+}
+
+epk::SlotPtrs host_slot_ptrs(ep_pool* p, int slot) {
+  char* b = p->d_ring + (size_t)slot * p->slot_stride;
+  epk::SlotPtrs s;
+  s.env_id = (int32_t*)(b + p->key_off[0]);
+  s.penv = (int32_t*)(b + p->key_off[1]);
+  s.elapsed = (int32_t*)(b + p->key_off[2]);
+  s.done = (uint8_t*)(b + p->key_off[3]);
+  s.reward = (float*)(b + p->key_off[4]);
+  s.discount = (float*)(b + p->key_off[5]);
+  s.step_type = (int32_t*)(b + p->key_off[6]);
+  s.trunc = (uint8_t*)(b + p->key_off[7]);
+  s.raw = (int32_t*)(b + p->key_off[8]);
+  s.pdone = (uint8_t*)(b + p->key_off[9]);
+  s.pid = (int32_t*)(b + p->key_off[10]);
+  return s;
+}
+
+epk::PoolConst pool_const(ep_pool* p) {
+  epk::PoolConst pc;
+  pc.N = p->N;
+  pc.env_off = p->cfg.env_id_offset;
+  pc.seed = p->cfg.seed;
+  pc.max_episode_steps = p->cfg.max_episode_steps;
+  pc.S = p->S;
+  return pc;
+}
+
+hipEvent_t get_event(ep_pool* p) {
+  if (!p->ev_pool.empty()) {
+    hipEvent_t e = p->ev_pool.back();
+    p->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct TimedScope {
+  ep_pool* p;
+  hipEvent_t a = nullptr, b = nullptr;
+  explicit TimedScope(ep_pool* pool) : p(pool) {
+    if (p->timing) {
+      a = get_event(p);
+      b = get_event(p);
+      if (a && b) (void)hipEventRecord(a, p->stream);
+    }
+  }
+  ~TimedScope() {
+    if (a && b) {
+      (void)hipEventRecord(b, p->stream);
+      p->timed.emplace_back(a, b);
+    }
+  }
+};
+
+int drain_timed(ep_pool* p) {
+  for (auto& ab : p->timed) {
+    HIP_TRY(hipEventSynchronize(ab.second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ab.first, ab.second));
+    p->timed_total_us += (double)ms * 1e3;
+    p->timed_launches += 1;
+    p->ev_pool.push_back(ab.first);
+    p->ev_pool.push_back(ab.second);
+  }
+  p->timed.clear();
+  return EP_OK;
+}
+
+// Is ring slot `slot` free for batch index `bi`? (the batch that used it before, bi - Q, must
+// have been received; reference: StateBuffer::Allocate throws once alloc_count_ >= batch_)
+bool slot_free_for(ep_pool* p, uint64_t bi) { return bi < p->done_ptr + (uint64_t)p->Q; }
+
+// Launch the single-player kernel for items [i0, i0+n) of one send/reset that land in `slot`
+// at rows row0...
+int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
+              int slot, int row0, bool force_reset) {
+  epk::StepArgs a;
+  a.env_id = d_env_id;
+  a.players_env_id = d_penv;
+  a.list_action = d_la;
+  a.env = p->d_env;
+  a.stats = p->stats;
+  a.slot = host_slot_ptrs(p, slot);
+  a.err = p->d_err + slot;
+  a.pc = pool_const(p);
+  a.n = n;
+  a.row0 = row0;
+  a.force_reset = force_reset ? 1 : 0;
+  dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
+  {
+    TimedScope ts(p);
+    if (p->S == 10)
+      hipLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, p->stream, a);
+    else
+      hipLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, p->stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return EP_OK;
+}
+
+// Common tail of send/reset once the action arrays are on the device.
+// `n` items; multi-player: `np_rows` rows in players.env_id.
+int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
+                   int n, int np_rows, bool force_reset) {
+  if (n == 0) return EP_OK;
+  const uint64_t B = (uint64_t)p->B;
+  // ring capacity check for every batch this call touches
+  uint64_t first_bi = p->alloc_count / B, last_bi = (p->alloc_count + (uint64_t)n - 1) / B;
+  for (uint64_t bi = first_bi; bi <= last_bi; ++bi)
+    if (!slot_free_for(p, bi))
+      return fail(EP_ERR_RING_FULL,
+                  "StateBuffer ring full: %d un-received batches (ring_depth=%d); call recv", p->Q,
+                  p->Q);
+  if (p->is_sync) p->stepping_env_num += n;  // async_envpool.h:73-75 / :185-187
+
+  if (p->P > 1) {
+    return epk_mp::enqueue_mp(p, d_env_id, d_penv, d_la, n, np_rows, force_reset);
+  }
+  int i0 = 0;
+  while (i0 < n) {
+    uint64_t pos = p->alloc_count;
+    uint64_t bi = pos / B;
+    int slot = (int)(bi % (uint64_t)p->Q);
+    int room = (int)(B - pos % B);
+    int cnt = std::min(room, n - i0);
+    // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
+    // otherwise rows follow the allocation order.
+    int row0 = p->is_sync ? i0 : (int)(pos % B);
+    int rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
+                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset);
+    if (rc != EP_OK) return rc;
+    SlotHost& sh = p->slots[slot];
+    sh.alloc_count += cnt;
+    sh.shared_off += cnt;
+    sh.written.emplace_back(row0, row0 + cnt);
+    sh.has_work = true;
+    HIP_TRY(hipEventRecord(sh.ready, p->stream));
+    p->alloc_count += cnt;
+    i0 += cnt;
+  }
+  return EP_OK;
+}
+
+// Copies `bytes` of host action data into the next pinned staging slot and enqueues the H2D
+// copy on the copy stream; the compute stream then waits for it.
+int stage_begin(ep_pool* p, int* out_idx) {
+  int a = (int)(p->stage_idx++ % (uint64_t)p->A);
+  HIP_TRY(hipEventSynchronize(p->stage_free[a]));  // the kernel that read this slot is done
+  *out_idx = a;
+  return EP_OK;
+}
+
+int stage_commit(ep_pool* p, int a, size_t bytes) {
+  char* h = p->h_stage + (size_t)a * p->stage_bytes;
+  char* d = p->d_stage + (size_t)a * p->stage_bytes;
+  HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, p->copy_stream));
+  HIP_TRY(hipEventRecord(p->stage_copied[a], p->copy_stream));
+  HIP_TRY(hipStreamWaitEvent(p->stream, p->stage_copied[a], 0));
+  return EP_OK;
+}
+
+int stage_release(ep_pool* p, int a) {
+  HIP_TRY(hipEventRecord(p->stage_free[a], p->stream));
+  return EP_OK;
+}
+
+int validate_ids_host(ep_pool* p, const int32_t* ids, int n) {
+  for (int i = 0; i < n; ++i) {
+    int64_t local = (int64_t)ids[i] - p->cfg.env_id_offset;
+    if (local < 0 || local >= p->N)
+      return fail(EP_ERR_INVALID, "env_id %d at position %d is outside this pool's shard [%d, %d)",
+                  ids[i], i, p->cfg.env_id_offset, p->cfg.env_id_offset + p->N);
+  }
+  return EP_OK;
+}
+
+}  // namespace
+
+#include "dummy_mp_host.inl"
+
+extern "C" {
+
+const char* ep_last_error(void) { return g_last_error.c_str(); }
+const char* ep_version(void) { return "envpool_amd 0.1 (gfx950)"; }
+
+int32_t ep_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
+  if (!cfg || !out) return fail(EP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->num_envs < 1) return fail(EP_ERR_INVALID, "num_envs must be >= 1, got %d", cfg->num_envs);
+  if (cfg->batch_size > cfg->num_envs)  // env_spec.h:74-79
+    return fail(EP_ERR_INVALID,
+                "It is required that batch_size <= num_envs, got num_envs = %d, batch_size = %d",
+                cfg->num_envs, cfg->batch_size);
+  if (cfg->batch_size < 0) return fail(EP_ERR_INVALID, "batch_size must be >= 0");
+  if (cfg->max_num_players < 1) return fail(EP_ERR_INVALID, "max_num_players must be >= 1");
+  if (cfg->state_num < 2) return fail(EP_ERR_INVALID, "state_num must be >= 2 (obs:raw has two live columns)");
+  int ndev = ep_device_count();
+  if (ndev <= 0)
+    return fail(EP_ERR_NO_DEVICE,
+                "no HIP device visible: envpool_amd has no CPU fallback (the CPU oracle lives in "
+                "oracle/ and is test infrastructure only)");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev)
+    return fail(EP_ERR_INVALID, "device_id %d out of range [0,%d)", cfg->device_id, ndev);
+
+  std::unique_ptr<ep_pool> p(new ep_pool());
+  p->cfg = *cfg;
+  p->N = cfg->num_envs;
+  p->B = cfg->batch_size == 0 ? cfg->num_envs : cfg->batch_size;  // env_spec.h:80-82
+  p->cfg.batch_size = p->B;
+  p->P = cfg->max_num_players;
+  p->S = cfg->state_num;
+  p->is_sync = (p->B == p->N && p->P == 1);  // async_envpool.h:95
+  int ref_depth = (p->N / p->B + 2) * 2;     // state_buffer_queue.h:68
+  p->Q = cfg->ring_depth > 0 ? cfg->ring_depth : ref_depth;
+  if (p->Q < 2) return fail(EP_ERR_INVALID, "ring_depth must be >= 2");
+  p->device = cfg->device_id;
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+
+  // slot layout
+  const size_t B = p->B, BP = (size_t)p->B * p->P;
+  const size_t rows[11] = {B, BP, B, B, BP, BP, B, B, BP, BP, BP};
+  size_t off = 0;
+  for (int k = 0; k < 11; ++k) {
+    p->key_off[k] = off;
+    p->key_rowbytes[k] = (size_t)kSlotElem[k] * (k == 8 ? (size_t)p->S : 1);
+    p->key_is_player[k] = rows[k] == BP && (k == 1 || k == 4 || k == 5 || k >= 8);
+    off += align_up(rows[k] * p->key_rowbytes[k]);
+  }
+  p->slot_stride = off;
+  if (p->slot_stride * (size_t)p->Q > ((size_t)200 << 30))
+    return fail(EP_ERR_TOO_LARGE, "StateBuffer ring of %zu bytes does not fit", p->slot_stride * (size_t)p->Q);
+  HIP_TRY(hipMalloc((void**)&p->d_ring, p->slot_stride * (size_t)p->Q));
+  HIP_TRY(hipMemsetAsync(p->d_ring, 0, p->slot_stride * (size_t)p->Q, p->stream));
+
+  // env state: state_ = 0, current_step_ = -1 (dummy_envpool.h:118, env.h:71)
+  HIP_TRY(hipMalloc((void**)&p->d_env, sizeof(epk::EnvRec) * (size_t)p->N));
+  {
+    std::vector<epk::EnvRec> init((size_t)p->N, epk::EnvRec{0, -1});
+    HIP_TRY(hipMemcpy(p->d_env, init.data(), sizeof(epk::EnvRec) * (size_t)p->N, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMalloc((void**)&p->stats.ep_return, 4 * (size_t)p->N));
+  HIP_TRY(hipMalloc((void**)&p->stats.fin_return, 4 * (size_t)p->N));
+  HIP_TRY(hipMalloc((void**)&p->stats.fin_length, 4 * (size_t)p->N));
+  HIP_TRY(hipMalloc((void**)&p->stats.ep_count, 4 * (size_t)p->N));
+  HIP_TRY(hipMemsetAsync(p->stats.ep_return, 0, 4 * (size_t)p->N, p->stream));
+  HIP_TRY(hipMemsetAsync(p->stats.fin_return, 0, 4 * (size_t)p->N, p->stream));
+  HIP_TRY(hipMemsetAsync(p->stats.fin_length, 0, 4 * (size_t)p->N, p->stream));
+  HIP_TRY(hipMemsetAsync(p->stats.ep_count, 0, 4 * (size_t)p->N, p->stream));
+
+  // error words: host-mapped so that a (rare) failure is visible after the slot's event
+  HIP_TRY(hipHostMalloc((void**)&p->h_err, sizeof(epk::ErrWords) * (size_t)p->Q, hipHostMallocMapped));
+  memset(p->h_err, 0, sizeof(epk::ErrWords) * (size_t)p->Q);
+  HIP_TRY(hipHostGetDevicePointer((void**)&p->d_err, p->h_err, 0));
+
+  // multi-player scratch
+  if (p->P > 1) {
+    size_t cap = (size_t)p->N;
+    HIP_TRY(hipMalloc((void**)&p->d_mp_counts, 4 * (size_t)p->N));
+    HIP_TRY(hipMemsetAsync(p->d_mp_counts, 0, 4 * (size_t)p->N, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->d_mp_np, 4 * cap));
+    HIP_TRY(hipMalloc((void**)&p->d_mp_off, 4 * cap));
+    HIP_TRY(hipMalloc((void**)&p->d_mp_items, sizeof(epk::MpItem) * cap));
+    HIP_TRY(hipMalloc((void**)&p->d_mp_base, 4));
+    HIP_TRY(hipMalloc((void**)&p->d_slot_players, 4 * (size_t)p->Q));
+    HIP_TRY(hipMemsetAsync(p->d_slot_players, 0, 4 * (size_t)p->Q, p->stream));
+    HIP_TRY(hipHostMalloc((void**)&p->h_slot_players, 4 * (size_t)p->Q, hipHostMallocDefault));
+    memset(p->h_slot_players, 0, 4 * (size_t)p->Q);
+  }
+
+  // action staging ring for host sends: env_id + players.env_id + list_action + 2 unused keys
+  p->A = 4;
+  p->stage_bytes = align_up(4 * (size_t)p->N) + align_up(4 * (size_t)p->N * p->P) +
+                   align_up(48 * (size_t)p->N) + 2 * align_up(4 * (size_t)p->N * p->P);
+  HIP_TRY(hipHostMalloc((void**)&p->h_stage, p->stage_bytes * (size_t)p->A, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void**)&p->d_stage, p->stage_bytes * (size_t)p->A));
+  p->stage_free.resize(p->A);
+  p->stage_copied.resize(p->A);
+  for (int a = 0; a < p->A; ++a) {
+    HIP_TRY(hipEventCreateWithFlags(&p->stage_free[a], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->stage_copied[a], hipEventDisableTiming));
+  }
+  p->slots.resize(p->Q);
+  for (auto& s : p->slots) HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+  p->blocks = std::make_shared<HostBlocks>();
+  p->blocks->bytes = p->slot_stride;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *out = p.release();
+  return EP_OK;
+}
+
+int ep_pool_destroy(ep_pool* p) {
+  if (!p) return EP_OK;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  (void)hipStreamSynchronize(p->copy_stream);
+  for (auto& ab : p->timed) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
+  for (auto e : p->ev_pool) (void)hipEventDestroy(e);
+  for (auto& s : p->slots) if (s.ready) (void)hipEventDestroy(s.ready);
+  for (auto e : p->stage_free) (void)hipEventDestroy(e);
+  for (auto e : p->stage_copied) (void)hipEventDestroy(e);
+  (void)hipFree(p->d_ring);
+  (void)hipFree(p->d_env);
+  (void)hipFree(p->stats.ep_return);
+  (void)hipFree(p->stats.fin_return);
+  (void)hipFree(p->stats.fin_length);
+  (void)hipFree(p->stats.ep_count);
+  (void)hipFree(p->d_mp_counts);
+  (void)hipFree(p->d_mp_np);
+  (void)hipFree(p->d_mp_off);
+  (void)hipFree(p->d_mp_items);
+  (void)hipFree(p->d_mp_base);
+  (void)hipFree(p->d_slot_players);
+  if (p->h_slot_players) (void)hipHostFree(p->h_slot_players);
+  if (p->h_err) (void)hipHostFree(p->h_err);
+  if (p->h_stage) (void)hipHostFree(p->h_stage);
+  (void)hipFree(p->d_stage);
+  {
+    std::lock_guard<std::mutex> lk(p->blocks->mu);
+    p->blocks->alive = false;
+    for (void* b : p->blocks->free_list) (void)hipHostFree(b);
+    p->blocks->free_list.clear();
+  }
+  (void)hipStreamDestroy(p->stream);
+  (void)hipStreamDestroy(p->copy_stream);
+  delete p;
+  return EP_OK;
+}
+
+int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
+  if (!p || (!env_ids && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad reset arguments");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if (n == 0) return EP_OK;
+  if (n > p->N) return fail(EP_ERR_INVALID, "reset of %d envs on a pool of %d", n, p->N);
+  if (mem == EP_MEM_DEVICE) return enqueue_slices(p, env_ids, nullptr, nullptr, n, 0, true);
+  if ((rc = validate_ids_host(p, env_ids, n))) return rc;
+  int a = 0;
+  if ((rc = stage_begin(p, &a))) return rc;
+  char* h = p->h_stage + (size_t)a * p->stage_bytes;
+  memcpy(h, env_ids, 4 * (size_t)n);
+  if ((rc = stage_commit(p, a, 4 * (size_t)n))) return rc;
+  rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true);
+  int rc2 = stage_release(p, a);
+  return rc ? rc : rc2;
+}
+
+int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims,
+                 int32_t mem) {
+  if (!p || !arrays || !leading_dims) return fail(EP_ERR_INVALID, "null argument");
+  if (n_arrays != 5)
+    return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays in _action_keys order, got %d", n_arrays);
+  const int64_t n = leading_dims[0], np_rows = leading_dims[1];
+  if (n < 0 || n > p->N) return fail(EP_ERR_INVALID, "env_id leading dim %lld not in [0,%d]", (long long)n, p->N);
+  if (leading_dims[2] != n)
+    return fail(EP_ERR_INVALID, "list_action leading dim %lld != env_id leading dim %lld",
+                (long long)leading_dims[2], (long long)n);
+  if (p->P == 1 && np_rows < n)
+    return fail(EP_ERR_INVALID, "players.env_id has %lld rows, need %lld", (long long)np_rows, (long long)n);
+  if (np_rows > (int64_t)p->N * p->P)
+    return fail(EP_ERR_INVALID, "players.env_id has %lld rows, more than num_envs*max_num_players", (long long)np_rows);
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if (n == 0) return EP_OK;
+  if (mem == EP_MEM_DEVICE) {
+    return enqueue_slices(p, (const int32_t*)arrays[0], (const int32_t*)arrays[1], (const double*)arrays[2],
+                          (int)n, (int)np_rows, false);
+  }
+  if ((rc = validate_ids_host(p, (const int32_t*)arrays[0], (int)n))) return rc;
+  int a = 0;
+  if ((rc = stage_begin(p, &a))) return rc;
+  char* h = p->h_stage + (size_t)a * p->stage_bytes;
+  char* d = p->d_stage + (size_t)a * p->stage_bytes;
+  size_t o0 = 0, o1 = align_up(4 * (size_t)n), o2 = o1 + align_up(4 * (size_t)np_rows);
+  size_t total = o2 + 48 * (size_t)n;
+  memcpy(h + o0, arrays[0], 4 * (size_t)n);
+  memcpy(h + o1, arrays[1], 4 * (size_t)np_rows);
+  memcpy(h + o2, arrays[2], 48 * (size_t)n);
+  // players.action / players.id (arrays[3], arrays[4]) are never read by DummyEnv::Step
+  // (dummy_envpool.h:173-210), so they are not shipped to the device.
+  if ((rc = stage_commit(p, a, total))) return rc;
+  rc = enqueue_slices(p, (const int32_t*)(d + o0), (const int32_t*)(d + o1), (const double*)(d + o2), (int)n,
+                      (int)np_rows, false);
+  int rc2 = stage_release(p, a);
+  return rc ? rc : rc2;
+}
+
+int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* arrays,
+                    const int64_t* leading_dims, const int64_t* step_stride_rows) {
+  if (!p || !arrays || !leading_dims || !step_stride_rows) return fail(EP_ERR_INVALID, "null argument");
+  if (n_arrays != 5) return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays, got %d", n_arrays);
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if (!p->is_sync)
+    return fail(EP_ERR_INVALID, "rollout needs sync mode (batch_size == num_envs, max_num_players == 1)");
+  if (T < 1 || T > p->Q) return fail(EP_ERR_INVALID, "rollout of %d steps needs 1 <= T <= ring_depth (%d)", T, p->Q);
+  if (leading_dims[0] != p->N || leading_dims[1] != p->N || leading_dims[2] != p->N)
+    return fail(EP_ERR_INVALID, "rollout steps ALL %d envs every step; got leading dims %lld/%lld/%lld", p->N,
+                (long long)leading_dims[0], (long long)leading_dims[1], (long long)leading_dims[2]);
+  if (step_stride_rows[0] != 0)
+    return fail(EP_ERR_INVALID, "rollout keeps the env_id array fixed across steps (step stride 0)");
+  if (p->alloc_count != p->done_ptr * (uint64_t)p->B || p->stepping_env_num != 0)
+    return fail(EP_ERR_INVALID, "rollout needs an empty queue: receive outstanding batches first");
+  epk::RolloutArgs a;
+  a.env_id = (const int32_t*)arrays[0];
+  a.players_env_id = (const int32_t*)arrays[1];
+  a.list_action = (const double*)arrays[2];
+  a.penv_stride = step_stride_rows[1];
+  a.la_stride = step_stride_rows[2];
+  a.env = p->d_env;
+  a.stats = p->stats;
+  a.ring.ring = p->d_ring;
+  a.ring.stride = p->slot_stride;
+  for (int k = 0; k < 11; ++k) a.ring.off[k] = (uint32_t)p->key_off[k];
+  a.ring.depth = p->Q;
+  uint64_t bi0 = p->alloc_count / (uint64_t)p->B;
+  a.slot0 = (int)(bi0 % (uint64_t)p->Q);
+  a.err = p->d_err + a.slot0;  // errors of the whole rollout are reported with its first batch
+  a.pc = pool_const(p);
+  a.T = T;
+  dim3 grid((p->N + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
+  {
+    TimedScope ts(p);
+    if (p->S == 10)
+      hipLaunchKernelGGL(epk::dummy_rollout_sp<10>, grid, block, 0, p->stream, a);
+    else
+      hipLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+  for (int t = 0; t < T; ++t) {
+    int slot = (int)((bi0 + (uint64_t)t) % (uint64_t)p->Q);
+    SlotHost& sh = p->slots[slot];
+    sh.alloc_count += p->B;
+    sh.shared_off += p->B;
+    sh.written.emplace_back(0, p->B);
+    sh.has_work = true;
+    HIP_TRY(hipEventRecord(sh.ready, p->stream));
+  }
+  p->alloc_count += (uint64_t)T * (uint64_t)p->B;
+  p->stepping_env_num += (int64_t)T * p->B;
+  return EP_OK;
+}
+
+int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  const int slot = (int)(p->done_ptr % (uint64_t)p->Q);
+  SlotHost& sh = p->slots[slot];
+  // async_envpool.h:163-166
+  int64_t additional = 0;
+  if (p->is_sync && p->stepping_env_num < p->B) additional = p->B - p->stepping_env_num;
+  if ((int64_t)sh.alloc_count + additional != p->B)
+    return fail(EP_ERR_WOULD_BLOCK,
+                "recv would block forever: head batch has %llu of %d env-steps outstanding "
+                "(the reference deadlocks in StateBuffer::Wait here)",
+                (unsigned long long)sh.alloc_count, p->B);
+  const uint32_t nrows = sh.shared_off;
+  uint32_t nplayers = nrows;
+  if (sh.has_work) HIP_TRY(hipEventSynchronize(sh.ready));
+  if (p->P > 1) {
+    HIP_TRY(hipMemcpyAsync(p->h_slot_players + slot, p->d_slot_players + slot, 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemsetAsync(p->d_slot_players + slot, 0, 4, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    nplayers = p->h_slot_players[slot];
+  }
+  // rows inside [0, nrows) that no kernel wrote must read as zero (fresh zeroed StateBuffer,
+  // array.h:77-81); only the reference's "several sync sends before one recv" corner gets here.
+  if (p->P == 1 && nrows > 0) {
+    std::sort(sh.written.begin(), sh.written.end());
+    int64_t cur = 0;
+    bool any = false;
+    auto zero_rows = [&](int64_t a, int64_t b) -> int {
+      for (int k = 0; k < 11; ++k) {
+        char* base = p->d_ring + (size_t)slot * p->slot_stride + p->key_off[k];
+        HIP_TRY(hipMemsetAsync(base + (size_t)a * p->key_rowbytes[k], 0, (size_t)(b - a) * p->key_rowbytes[k], p->stream));
+      }
+      any = true;
+      return EP_OK;
+    };
+    for (auto& w : sh.written) {
+      if (w.first > cur && cur < (int64_t)nrows)
+        if ((rc = zero_rows(cur, std::min<int64_t>(w.first, nrows)))) return rc;
+      cur = std::max(cur, w.second);
+    }
+    if (cur < (int64_t)nrows)
+      if ((rc = zero_rows(cur, nrows))) return rc;
+    if (any) HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  int status = EP_OK;
+  if (p->h_err[slot].action_check) {
+    status = fail(EP_ERR_ACTION_CHECK,
+                  "Dummy action self-check failed: list_action lanes differ (the reference aborts "
+                  "here, dummy_envpool.h:189-192)");
+  } else if (p->h_err[slot].env_id_range) {
+    status = fail(EP_ERR_ACTION_CHECK, "an env_id in the sent batch is outside this pool's shard");
+  }
+  p->h_err[slot].action_check = 0;
+  p->h_err[slot].env_id_range = 0;
+
+  memset(out, 0, sizeof(*out));
+  out->num_keys = 12;
+  out->mem = mem;
+  out->num_rows = (int32_t)nrows;
+  out->num_player_rows = (int32_t)nplayers;
+  out->seq = p->recv_seq++;
+  char* base = nullptr;
+  if (mem == EP_MEM_HOST) {
+    void* blk = nullptr;
+    {
+      std::lock_guard<std::mutex> bl(p->blocks->mu);
+      if (!p->blocks->free_list.empty()) {
+        blk = p->blocks->free_list.back();
+        p->blocks->free_list.pop_back();
+      }
+    }
+    if (!blk) HIP_TRY(hipHostMalloc(&blk, p->slot_stride, hipHostMallocDefault));
+    char* src = p->d_ring + (size_t)slot * p->slot_stride;
+    if ((size_t)nrows * 2 >= (size_t)p->B) {
+      HIP_TRY(hipMemcpyAsync(blk, src, p->slot_stride, hipMemcpyDeviceToHost, p->stream));
+    } else {
+      for (int k = 0; k < 11; ++k) {
+        size_t r = p->key_is_player[k] ? nplayers : nrows;
+        if (r) HIP_TRY(hipMemcpyAsync((char*)blk + p->key_off[k], src + p->key_off[k], r * p->key_rowbytes[k], hipMemcpyDeviceToHost, p->stream));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    out->owner = new HostBlockOwner{p->blocks, blk};
+    base = (char*)blk;
+  } else {
+    base = p->d_ring + (size_t)slot * p->slot_stride;
+  }
+  for (int k = 0; k < 12; ++k) {
+    ep_array& a = out->arrays[k];
+    int sk = kStateToSlot[k];
+    if (sk < 0) {  // obs:dyn — implicit: row r is full((info:players.env_id[r]+1, S), that id)
+      a.data = nullptr;
+      a.dtype = EP_CONTAINER_I32;
+      a.ndim = 1;
+      a.shape[0] = nplayers;
+      continue;
+    }
+    a.data = base + p->key_off[sk];
+    a.dtype = kSlotDtype[sk];
+    a.ndim = 1;
+    a.shape[0] = p->key_is_player[sk] ? nplayers : nrows;
+    if (sk == 8) { a.ndim = 2; a.shape[1] = p->S; }
+  }
+  // StateBufferQueue::Wait tail (state_buffer_queue.h:141-149) + AsyncEnvPool::Recv (:170-172)
+  p->done_ptr++;
+  if (additional > 0) p->alloc_count += (uint64_t)additional;
+  sh.alloc_count = 0;
+  sh.shared_off = 0;
+  sh.written.clear();
+  sh.has_work = false;
+  if (p->is_sync) p->stepping_env_num -= nrows;
+  return status;
+}
+
+int ep_batch_release(ep_batch* b) {
+  if (!b || !b->owner) return EP_OK;
+  HostBlockOwner* o = (HostBlockOwner*)b->owner;
+  {
+    std::lock_guard<std::mutex> lk(o->home->mu);
+    if (o->home->alive && o->home->free_list.size() < 8) o->home->free_list.push_back(o->ptr);
+    else (void)hipHostFree(o->ptr);
+  }
+  delete o;
+  b->owner = nullptr;
+  return EP_OK;
+}
+
+int ep_pool_sync(ep_pool* p) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(p->copy_stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return EP_OK;
+}
+
+int ep_pool_episode_stats(ep_pool* p, float* fin_return, int32_t* fin_length, int32_t* ep_count, int32_t mem) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  hipMemcpyKind kind = mem == EP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  size_t bytes = 4 * (size_t)p->N;
+  if (fin_return) HIP_TRY(hipMemcpyAsync(fin_return, p->stats.fin_return, bytes, kind, p->stream));
+  if (fin_length) HIP_TRY(hipMemcpyAsync(fin_length, p->stats.fin_length, bytes, kind, p->stream));
+  if (ep_count) HIP_TRY(hipMemcpyAsync(ep_count, p->stats.ep_count, bytes, kind, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return EP_OK;
+}
+
+int64_t ep_pool_checkpoint_bytes(ep_pool* p) {
+  if (!p) return 0;
+  return (int64_t)((sizeof(epk::EnvRec) + 16) * (size_t)p->N);
+}
+
+int ep_pool_checkpoint_save(ep_pool* p, void* buf) {
+  if (!p || !buf) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  char* o = (char*)buf;
+  size_t n = (size_t)p->N;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemcpy(o, p->d_env, 8 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o + 8 * n, p->stats.ep_return, 4 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o + 12 * n, p->stats.fin_return, 4 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o + 16 * n, p->stats.fin_length, 4 * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o + 20 * n, p->stats.ep_count, 4 * n, hipMemcpyDeviceToHost));
+  return EP_OK;
+}
+
+int ep_pool_checkpoint_restore(ep_pool* p, const void* buf) {
+  if (!p || !buf) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  const char* o = (const char*)buf;
+  size_t n = (size_t)p->N;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemcpy(p->d_env, o, 8 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->stats.ep_return, o + 8 * n, 4 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->stats.fin_return, o + 12 * n, 4 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->stats.fin_length, o + 16 * n, 4 * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->stats.ep_count, o + 20 * n, 4 * n, hipMemcpyHostToDevice));
+  return EP_OK;
+}
+
+int32_t ep_pool_num_envs(ep_pool* p) { return p ? p->N : 0; }
+int32_t ep_pool_batch_size(ep_pool* p) { return p ? p->B : 0; }
+int32_t ep_pool_ring_depth(ep_pool* p) { return p ? p->Q : 0; }
+int32_t ep_pool_is_sync(ep_pool* p) { return p ? (p->is_sync ? 1 : 0) : 0; }
+void* ep_pool_stream(ep_pool* p) { return p ? (void*)p->stream : nullptr; }
+
+int ep_pool_set_timing(ep_pool* p, int32_t enabled) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  p->timing = enabled != 0;
+  return EP_OK;
+}
+
+int ep_pool_kernel_time_us(ep_pool* p, double* total_us, int64_t* launches, int32_t reset) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if ((rc = drain_timed(p))) return rc;
+  if (total_us) *total_us = p->timed_total_us;
+  if (launches) *launches = p->timed_launches;
+  if (reset) { p->timed_total_us = 0; p->timed_launches = 0; }
+  return EP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// py_dummy.cpp — pybind11 module `dummy_envpool`: the drop-in `_DummyEnvSpec` /
+// `_DummyEnvPool` classes of envpool2/dummy/dummy_envpool.cpp:25-31 (REGISTER macro,
+// envpool2/core/py_envpool.h:268-287), implemented over the C ABI in
+// include/envpool_amd.h. No HIP here: this file is host glue only.
+#include <cstring>
+
+#include "py_common.h"
+
+namespace {
+
+// Config keys in the reference's order (env_spec.h:25-30 ++ dummy_envpool.h:47-49); the
+// three build-only keys come last so positional 11-tuples of the reference still work.
+const std::vector<std::string> kConfigKeys = {
+    "num_envs", "batch_size", "num_threads", "max_num_players", "thread_affinity_offset",
+    "base_path", "seed", "gym_reset_return_info", "max_episode_steps", "state_num", "action_num",
+    "device_id", "env_id_offset", "ring_depth"};
+const std::vector<std::string> kStateKeys = {
+    "info:env_id", "info:players.env_id", "elapsed_step", "done", "reward", "discount",
+    "step_type", "trunc", "obs:raw", "obs:dyn", "info:players.done", "info:players.id"};
+const std::vector<std::string> kActionKeys = {"env_id", "players.env_id", "list_action",
+                                              "players.action", "players.id"};
+
+py::tuple default_config_values() {
+  return py::make_tuple(1, 0, 0, 1, -1, std::string("envpool2"), 42, false,
+                        std::numeric_limits<int>::max(), 10, 6, 0, 0, 0);
+}
+
+struct DummySpec {
+  ep_dummy_config cfg{};
+  std::string base_path;
+  bool gym_reset_return_info = false;
+  py::tuple config_values, state_spec, action_spec;
+
+  explicit DummySpec(const py::tuple& conf) {
+    py::tuple def = default_config_values();
+    const size_t n = conf.size();
+    if (n != 11 && n != kConfigKeys.size())
+      throw std::invalid_argument("_DummyEnvSpec expects a config tuple of 11 (reference) or 14 values");
+    auto get = [&](size_t i) -> py::object { return i < n ? py::object(conf[i]) : py::object(def[i]); };
+    cfg.num_envs = get(0).cast<int>();
+    cfg.batch_size = get(1).cast<int>();
+    cfg.num_threads = get(2).cast<int>();
+    cfg.max_num_players = get(3).cast<int>();
+    cfg.thread_affinity_offset = get(4).cast<int>();
+    base_path = get(5).cast<std::string>();
+    cfg.seed = get(6).cast<int>();
+    gym_reset_return_info = get(7).cast<bool>();
+    cfg.max_episode_steps = get(8).cast<int>();
+    cfg.state_num = get(9).cast<int>();
+    cfg.action_num = get(10).cast<int>();
+    cfg.device_id = get(11).cast<int>();
+    cfg.env_id_offset = get(12).cast<int>();
+    cfg.ring_depth = get(13).cast<int>();
+    // env_spec.h:74-82
+    if (cfg.batch_size > cfg.num_envs)
+      throw std::invalid_argument("It is required that batch_size <= num_envs, got num_envs = " +
+                                  std::to_string(cfg.num_envs) +
+                                  ", batch_size = " + std::to_string(cfg.batch_size));
+    if (cfg.batch_size == 0) cfg.batch_size = cfg.num_envs;
+    config_values = py::make_tuple(cfg.num_envs, cfg.batch_size, cfg.num_threads, cfg.max_num_players,
+                                   cfg.thread_affinity_offset, base_path, cfg.seed, gym_reset_return_info,
+                                   cfg.max_episode_steps, cfg.state_num, cfg.action_num, cfg.device_id,
+                                   cfg.env_id_offset, cfg.ring_depth);
+    using epy::spec_entry;
+    const int S = cfg.state_num;
+    // env_spec.h:36-42 ++ dummy_envpool.h:76-84
+    state_spec = py::make_tuple(
+        spec_entry<int>({}), spec_entry<int>({-1}), spec_entry<int>({}), spec_entry<bool>({}),
+        spec_entry<float>({-1}), spec_entry<float>({-1}, py::make_tuple(0.0f, 1.0f)),
+        spec_entry<int>({}), spec_entry<bool>({}), spec_entry<int>({-1, S}),
+        epy::container_entry<int>({-1}, {-1, S}), spec_entry<bool>({-1}),
+        spec_entry<int>({-1}, py::make_tuple(0, cfg.max_num_players)));
+    // env_spec.h:33-34 ++ dummy_envpool.h:98-103
+    action_spec = py::make_tuple(spec_entry<int>({}), spec_entry<int>({-1}), spec_entry<double>({6}),
+                                 spec_entry<int>({-1}), spec_entry<int>({-1}));
+  }
+};
+
+// Above this many envs obs:dyn is handed out lazily (it is O(N^2) bytes).
+constexpr int kEagerDynMaxEnvId = 1024;
+
+struct DummyPool {
+  DummySpec spec;
+  ep_pool* pool = nullptr;
+
+  explicit DummyPool(const DummySpec& s) : spec(s) {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_dummy_pool_create(&spec.cfg, &pool);
+    }
+    epy::check(rc);
+  }
+  ~DummyPool() {
+    if (pool) {
+      py::gil_scoped_release rel;
+      ep_pool_destroy(pool);
+    }
+  }
+  DummyPool(const DummyPool&) = delete;
+
+  // PyEnvPool::PySend (py_envpool.h:219-225): force-cast to the spec dtype, C-contiguous.
+  void send(const std::vector<py::array>& action) {
+    if (action.size() != 5) throw std::invalid_argument("Dummy expects 5 action arrays");
+    py::array_t<int32_t, py::array::c_style | py::array::forcecast> a0(action[0]);
+    py::array_t<int32_t, py::array::c_style | py::array::forcecast> a1(action[1]);
+    py::array_t<double, py::array::c_style | py::array::forcecast> a2(action[2]);
+    py::array_t<int32_t, py::array::c_style | py::array::forcecast> a3(action[3]);
+    py::array_t<int32_t, py::array::c_style | py::array::forcecast> a4(action[4]);
+    if (a2.ndim() != 2 || a2.shape(1) != 6) throw std::invalid_argument("list_action must have shape (n, 6)");
+    const void* ptrs[5] = {a0.data(), a1.data(), a2.data(), a3.data(), a4.data()};
+    int64_t dims[5] = {a0.ndim() ? a0.shape(0) : 1, a1.ndim() ? a1.shape(0) : 1, a2.shape(0),
+                       a3.ndim() ? a3.shape(0) : 1, a4.ndim() ? a4.shape(0) : 1};
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_send(pool, 5, ptrs, dims, EP_MEM_HOST);
+    }
+    epy::check(rc);
+  }
+
+  // PyEnvPool::PyReset (py_envpool.h:246-251)
+  void reset(const py::array& env_ids) {
+    py::array_t<int32_t, py::array::c_style | py::array::forcecast> ids(env_ids);
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_reset(pool, ids.data(), (int32_t)ids.size(), EP_MEM_HOST);
+    }
+    epy::check(rc);
+  }
+
+  py::object make_dyn(const py::array& players_env_id) {
+    const int S = spec.cfg.state_num;
+    const auto n = players_env_id.shape(0);
+    const int32_t* ids = static_cast<const int32_t*>(players_env_id.data());
+    if (spec.cfg.env_id_offset + spec.cfg.num_envs <= kEagerDynMaxEnvId) {
+      // exact object array of arrays (py_envpool.h:50-77); row r = full((id+1, S), id)
+      // (dummy_envpool.h:154-162, 205-208)
+      py::array out(py::dtype("object"), std::vector<py::ssize_t>{n});
+      auto** cells = static_cast<PyObject**>(out.mutable_data());
+      for (py::ssize_t r = 0; r < n; ++r) {
+        py::array_t<int32_t> inner({(py::ssize_t)ids[r] + 1, (py::ssize_t)S});
+        std::fill(inner.mutable_data(), inner.mutable_data() + inner.size(), ids[r]);
+        Py_XDECREF(cells[r]);
+        cells[r] = inner.release().ptr();
+      }
+      return std::move(out);
+    }
+    py::object lazy = py::module_::import("envpool_amd.python.lazy").attr("LazyDyn");
+    return lazy(players_env_id, S);
+  }
+
+  // PyEnvPool::PyRecv (py_envpool.h:230-241)
+  std::vector<py::object> recv() {
+    auto holder = std::make_shared<epy::BatchHolder>();
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_recv(pool, EP_MEM_HOST, &holder->batch);
+    }
+    if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
+    std::string deferred = rc == EP_ERR_ACTION_CHECK ? ep_last_error() : "";
+    std::vector<py::object> ret;
+    ret.reserve(12);
+    for (int k = 0; k < holder->batch.num_keys; ++k) {
+      const ep_array& a = holder->batch.arrays[k];
+      if (a.dtype == EP_CONTAINER_I32) ret.emplace_back(py::none());
+      else ret.emplace_back(epy::view_of(holder, a));
+    }
+    ret[9] = make_dyn(py::array(ret[1]));
+    if (!deferred.empty()) throw std::runtime_error(deferred);
+    return ret;
+  }
+
+  // Additive API: zero-copy device views, as (ptr, shape, typestr) descriptors in
+  // _state_keys order (None for obs:dyn). See envpool_amd/interop.py.
+  py::tuple recv_device() {
+    ep_batch b;
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_recv(pool, EP_MEM_DEVICE, &b);
+    }
+    if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
+    std::string deferred = rc == EP_ERR_ACTION_CHECK ? ep_last_error() : "";
+    py::list out;
+    for (int k = 0; k < b.num_keys; ++k) {
+      if (b.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
+      else out.append(epy::device_desc(b.arrays[k]));
+    }
+    if (!deferred.empty()) throw std::runtime_error(deferred);
+    return py::make_tuple(out, b.num_rows, b.num_player_rows);
+  }
+
+  void send_device(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims) {
+    if (ptrs.size() != 5 || dims.size() != 5) throw std::invalid_argument("need 5 pointers and 5 dims");
+    const void* p[5];
+    for (int i = 0; i < 5; ++i) p[i] = reinterpret_cast<const void*>(ptrs[i]);
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_send(pool, 5, p, dims.data(), EP_MEM_DEVICE);
+    }
+    epy::check(rc);
+  }
+
+  void rollout(int T, const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims,
+               const std::vector<int64_t>& strides) {
+    if (ptrs.size() != 5 || dims.size() != 5 || strides.size() != 5)
+      throw std::invalid_argument("need 5 pointers, dims and strides");
+    const void* p[5];
+    for (int i = 0; i < 5; ++i) p[i] = reinterpret_cast<const void*>(ptrs[i]);
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_rollout(pool, T, 5, p, dims.data(), strides.data());
+    }
+    epy::check(rc);
+  }
+
+  py::tuple episode_stats() {
+    const int n = ep_pool_num_envs(pool);
+    py::array_t<float> ret(n);
+    py::array_t<int32_t> len(n), cnt(n);
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_episode_stats(pool, ret.mutable_data(), len.mutable_data(), cnt.mutable_data(), EP_MEM_HOST);
+    }
+    epy::check(rc);
+    return py::make_tuple(ret, len, cnt);
+  }
+
+  py::bytes checkpoint_save() {
+    std::string buf((size_t)ep_pool_checkpoint_bytes(pool), '\0');
+    epy::check(ep_pool_checkpoint_save(pool, buf.data()));
+    return py::bytes(buf);
+  }
+  void checkpoint_restore(const py::bytes& b) {
+    std::string buf = b;
+    if ((int64_t)buf.size() != ep_pool_checkpoint_bytes(pool))
+      throw std::invalid_argument("checkpoint size does not match this pool");
+    epy::check(ep_pool_checkpoint_restore(pool, buf.data()));
+  }
+  void sync() { py::gil_scoped_release rel; epy::check(ep_pool_sync(pool)); }
+  uintptr_t stream() { return reinterpret_cast<uintptr_t>(ep_pool_stream(pool)); }
+  uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(dummy_envpool, m) {
+  py::object abc_meta = py::module_::import("abc").attr("ABCMeta");  // py_envpool.h:261
+  py::class_<DummySpec>(m, "_DummyEnvSpec", py::metaclass(abc_meta))
+      .def(py::init<const py::tuple&>())
+      .def_readonly("_config_values", &DummySpec::config_values)
+      .def_readonly("_state_spec", &DummySpec::state_spec)
+      .def_readonly("_action_spec", &DummySpec::action_spec)
+      .def_property_readonly_static("_state_keys", [](py::object) { return kStateKeys; })
+      .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
+      .def_property_readonly_static("_config_keys", [](py::object) { return kConfigKeys; })
+      .def_property_readonly_static("_default_config_values", [](py::object) { return default_config_values(); });
+  py::class_<DummyPool>(m, "_DummyEnvPool", py::metaclass(abc_meta))
+      .def(py::init<const DummySpec&>())
+      .def_readonly("_spec", &DummyPool::spec)
+      .def("_recv", &DummyPool::recv)
+      .def("_send", &DummyPool::send)
+      .def("_reset", &DummyPool::reset)
+      .def_property_readonly_static("_state_keys", [](py::object) { return kStateKeys; })
+      .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
+      // additive (no reference counterpart)
+      .def("_recv_device", &DummyPool::recv_device)
+      .def("_send_device", &DummyPool::send_device)
+      .def("_rollout", &DummyPool::rollout)
+      .def("_episode_stats", &DummyPool::episode_stats)
+      .def("_checkpoint_save", &DummyPool::checkpoint_save)
+      .def("_checkpoint_restore", &DummyPool::checkpoint_restore)
+      .def("_sync", &DummyPool::sync)
+      .def("_stream", &DummyPool::stream)
+      .def("_handle", &DummyPool::handle);
+  m.def("device_count", []() { return ep_device_count(); });
+}

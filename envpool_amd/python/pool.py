@@ -1,0 +1,215 @@
+"""Python front-end of an EnvPool (counterpart of envpool2/python/envpool.py:28-174 and the
+`_to` converters of gym_envpool.py:74-95, gymnasium_envpool.py:73-88, dm_envpool.py:72-86)."""
+import pprint
+import warnings
+from collections import namedtuple
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from .spec import check_unique
+from .tree import Layout
+
+try:  # dm_env is optional; the local TimeStep has the same fields and helpers
+  from dm_env import TimeStep
+except ImportError:
+
+  class TimeStep(namedtuple("TimeStep", ["step_type", "reward", "discount", "observation"])):
+    __slots__ = ()
+
+    def first(self):
+      return self.step_type == 0
+
+    def mid(self):
+      return self.step_type == 1
+
+    def last(self):
+      return self.step_type == 2
+
+
+def _gym_is_new_api() -> bool:
+  try:
+    import gym
+    from packaging import version
+    return version.parse(gym.__version__) >= version.parse("0.26.0")
+  except ImportError:
+    return True
+
+
+def _flatten_action(action: Dict[str, Any], prefix: str = "") -> Dict[str, Any]:
+  flat = {}
+  for k, v in action.items():
+    key = f"{prefix}.{k}" if prefix else k
+    if isinstance(v, dict):
+      flat.update(_flatten_action(v, key))
+    else:
+      flat[key] = v
+  return flat
+
+
+class EnvPoolFrontEnd:
+  """send / recv / step / reset over the raw `_send/_recv/_reset` of the pybind class."""
+
+  _flavour = "raw"
+
+  def __init__(self, spec):
+    super().__init__(spec)
+    self.spec = spec
+    check_unique(type(self).__name__, "state", list(self._state_keys))
+    check_unique(type(self).__name__, "action", list(self._action_keys))
+    self._layout = Layout(self._state_keys)
+    self._dm_layout = Layout(self._state_keys, root="State", merge_info_into_obs=True)
+    self._action_checked = False
+
+  # ---- properties ----
+  def __len__(self) -> int:
+    return self.config["num_envs"]
+
+  @property
+  def config(self) -> Dict[str, Any]:
+    return dict(zip(self._spec._config_keys, self._spec._config_values))
+
+  @property
+  def all_env_ids(self) -> np.ndarray:
+    if not hasattr(self, "_all_env_ids"):
+      off = self.config.get("env_id_offset", 0)
+      self._all_env_ids = np.arange(off, off + self.config["num_envs"], dtype=np.int32)
+    return self._all_env_ids
+
+  @property
+  def is_async(self) -> bool:
+    c = self.config
+    return c["batch_size"] > 0 and c["num_envs"] != c["batch_size"]
+
+  def seed(self, seed=None) -> None:
+    warnings.warn("`seed` is abandoned; pass make(..., seed=seed) instead.", stacklevel=2)
+
+  # ---- action marshalling (envpool.py:33-85) ----
+  def _check_action(self, actions: List[np.ndarray]) -> None:
+    if self._action_checked:
+      return
+    self._action_checked = True
+    for a, (k, v) in zip(actions, self.spec.action_array_spec.items()):
+      if v.dtype != a.dtype:
+        raise RuntimeError(f'Expected dtype {v.dtype} with action "{k}", got {a.dtype}')
+      shape = tuple(v.shape)
+      if len(shape) > 0 and shape[0] == -1:
+        if a.shape[1:] != shape[1:]:
+          raise RuntimeError(f'Expected shape {shape} with action "{k}", got {a.shape}')
+      elif len(a.shape) == 0 or a.shape[1:] != shape:
+        raise RuntimeError(f'Expected shape {("num_env", *shape)} with action "{k}", got {a.shape}')
+
+  def _from(self, action, env_id: Optional[np.ndarray] = None) -> List[np.ndarray]:
+    keys = self._spec._action_keys
+    if isinstance(action, dict):
+      adict = _flatten_action(action)
+    else:
+      last_dtype = self._spec._action_spec[-1][0]
+      if isinstance(action, np.ndarray):
+        action = action.astype(last_dtype, order="C")
+      adict = {keys[-1]: action}
+    if env_id is None:
+      adict.setdefault("env_id", self.all_env_ids)
+    else:
+      adict["env_id"] = env_id.astype(np.int32)
+    adict.setdefault("players.env_id", adict["env_id"])
+    return [adict[k] for k in keys]
+
+  # ---- the API ----
+  def send(self, action, env_id: Optional[np.ndarray] = None) -> None:
+    arrays = self._from(action, env_id)
+    self._check_action(arrays)
+    self._send(arrays)
+
+  def recv(self, reset: bool = False, return_info: bool = True):
+    return self._to(self._recv(), reset, return_info)
+
+  def async_reset(self) -> None:
+    self._reset(self.all_env_ids)
+
+  def step(self, action, env_id: Optional[np.ndarray] = None):
+    self.send(action, env_id)
+    return self.recv(reset=False, return_info=True)
+
+  def reset(self, env_id: Optional[np.ndarray] = None):
+    if env_id is None:
+      env_id = self.all_env_ids
+    self._reset(env_id)
+    return self.recv(reset=True, return_info=self.config["gym_reset_return_info"])
+
+  def xla(self):
+    raise RuntimeError("XLA is disabled (jax is not part of this build).")
+
+  def __repr__(self) -> str:
+    cfg = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())
+    return f"{type(self).__name__}({cfg})"
+
+  __str__ = __repr__
+
+  # ---- output shaping ----
+  def _to(self, values, reset: bool, return_info: bool):
+    state = self._layout.build_dict(values)
+    info = state["info"]
+    info["elapsed_step"] = state["elapsed_step"]
+    if reset:
+      return state["obs"], info
+    terminated = state["done"] & ~state["trunc"]
+    return state["obs"], state["reward"], terminated, state["trunc"], info
+
+
+class GymnasiumFrontEnd(EnvPoolFrontEnd):
+  _flavour = "gymnasium"
+
+  @property
+  def observation_space(self):
+    return self.spec.gymnasium_observation_space
+
+  @property
+  def action_space(self):
+    return self.spec.gymnasium_action_space
+
+
+class GymFrontEnd(EnvPoolFrontEnd):
+  _flavour = "gym"
+
+  @property
+  def observation_space(self):
+    return self.spec.observation_space
+
+  @property
+  def action_space(self):
+    return self.spec.action_space
+
+  def _to(self, values, reset: bool, return_info: bool):
+    new_api = _gym_is_new_api()
+    state = self._layout.build_dict(values)
+    if reset and not (return_info or new_api):
+      return state["obs"]
+    info = state["info"]
+    if not new_api:
+      info["TimeLimit.truncated"] = state["trunc"]
+    info["elapsed_step"] = state["elapsed_step"]
+    if reset:
+      return state["obs"], info
+    if new_api:
+      return state["obs"], state["reward"], state["done"] & ~state["trunc"], state["trunc"], info
+    return state["obs"], state["reward"], state["done"], info
+
+
+class DMFrontEnd(EnvPoolFrontEnd):
+  _flavour = "dm"
+
+  def observation_spec(self):
+    return self.spec.observation_spec()
+
+  def action_spec(self):
+    return self.spec.action_spec()
+
+  def _to(self, values, reset: bool, return_info: bool):
+    state = self._dm_layout.build_namedtuple("State", values)
+    return TimeStep(step_type=state.step_type, reward=state.reward, discount=state.discount,
+                    observation=state.State)
+
+
+def make_pool_class(name: str, base: type, front: type) -> type:
+  return type(base)(name, (front, base), {})

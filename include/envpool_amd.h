@@ -1,0 +1,201 @@
+/*
+ * envpool_amd.h — C ABI of the MI355X-native envpool2 hot path.
+ *
+ * This is the drop-in boundary. Everything above it (pybind11 classes
+ * `_DummyEnvSpec` / `_DummyEnvPool`, the Python `make` / `send` / `recv` /
+ * `step` / `reset` layer) is host glue; everything below it is HIP for gfx950.
+ * No torch / pybind / C++ types cross this boundary: plain pointers, sizes and
+ * status codes only.
+ *
+ * The reference has no FFI layer of its own for this path: its boundary is the
+ * templated C++ class `PyEnvPool<AsyncEnvPool<DummyEnv>>`
+ * (envpool2/core/py_envpool.h:204-252) whose three entry points are
+ * `PySend` (:219-225), `PyRecv` (:230-241) and `PyReset` (:246-251). Each entry
+ * point below cites the reference interface it replaces.
+ *
+ * Threading contract (same as the reference, state_buffer_queue.h:131-138 and
+ * action_buffer_queue.h:60): `ep_pool_send` / `ep_pool_reset` may be called
+ * from several threads (they are serialised inside); `ep_pool_recv` has a
+ * single consumer.
+ */
+#ifndef ENVPOOL_AMD_H_
+#define ENVPOOL_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  EP_OK = 0,
+  EP_ERR_INVALID = 1,      /* bad argument; std::invalid_argument in the reference */
+  EP_ERR_HIP = 2,          /* a HIP runtime call failed */
+  EP_ERR_NO_DEVICE = 3,    /* no gfx950 device visible: the product path has no CPU fallback */
+  EP_ERR_WOULD_BLOCK = 4,  /* recv would wait forever (reference: deadlock in StateBuffer::Wait) */
+  EP_ERR_RING_FULL = 5,    /* more un-received batches than ring slots (reference: std::out_of_range,
+                              state_buffer.h:111) */
+  EP_ERR_ACTION_CHECK = 6, /* Dummy list_action lanes differ (reference: glog CHECK_EQ abort,
+                              dummy_envpool.h:189-192) or env_id out of range */
+  EP_ERR_TOO_LARGE = 7
+};
+
+/* ---- memory kinds --------------------------------------------------------- */
+enum {
+  EP_MEM_HOST = 0,  /* pointers are host memory (numpy); send copies, recv hands out a fresh host block */
+  EP_MEM_DEVICE = 1 /* pointers are device memory on the pool's GPU; zero-copy both ways */
+};
+
+/* ---- element types -------------------------------------------------------- */
+enum {
+  EP_I32 = 0,
+  EP_F32 = 1,
+  EP_F64 = 2,
+  EP_BOOL = 3, /* 1 byte, 0/1 */
+  EP_U8 = 4,
+  EP_CONTAINER_I32 = 5 /* ragged Container<int> (spec.h:96-109): no device array, see obs:dyn */
+};
+
+#define EP_MAX_KEYS 20
+#define EP_MAX_NDIM 4
+
+typedef struct ep_pool ep_pool; /* opaque */
+
+/* One returned array. Row-major, leading dim = rows actually returned
+ * (state_buffer.h:146-156 Truncate). `data` is NULL for EP_CONTAINER_I32. */
+typedef struct {
+  void* data;
+  int64_t shape[EP_MAX_NDIM];
+  int32_t ndim;
+  int32_t dtype;
+} ep_array;
+
+/* One received batch == one StateBuffer of the reference (state_buffer.h:40). */
+typedef struct {
+  int32_t num_keys;        /* arrays[0..num_keys) in `_state_keys` order */
+  int32_t mem;             /* EP_MEM_HOST or EP_MEM_DEVICE */
+  int32_t num_rows;        /* shared_offset: envs in this batch */
+  int32_t num_player_rows; /* player_offset: players in this batch */
+  uint64_t seq;            /* index of this batch since pool creation */
+  void* owner;             /* host block to free with ep_batch_release (host mem), else NULL */
+  ep_array arrays[EP_MAX_KEYS];
+} ep_batch;
+
+/* ---- Dummy-v0 ------------------------------------------------------------- */
+
+/* Config of the Dummy pool. First eleven fields are the reference's config keys
+ * (env_spec.h:25-30 ++ dummy_envpool.h:47-49) minus the two that are host-only
+ * strings/flags (`base_path`, `gym_reset_return_info`, kept by the pybind
+ * layer). Build-only keys come after them. */
+typedef struct {
+  int32_t num_envs;               /* envs owned by THIS pool (local shard) */
+  int32_t batch_size;             /* 0 => num_envs (env_spec.h:80-82) */
+  int32_t num_threads;            /* accepted, unused: there is no worker thread pool */
+  int32_t max_num_players;
+  int32_t thread_affinity_offset; /* accepted, unused */
+  int32_t seed;
+  int32_t max_episode_steps;
+  int32_t state_num;
+  int32_t action_num;
+  /* build-only */
+  int32_t device_id;     /* HIP device ordinal */
+  int32_t env_id_offset; /* global env_id of local env 0 (multi-GPU shard: env.h:94 seed_ = seed + GLOBAL id) */
+  int32_t ring_depth;    /* StateBuffer ring slots; 0 => reference rule (num_envs/batch+2)*2
+                            (state_buffer_queue.h:68) */
+} ep_dummy_config;
+
+/* Replaces: AsyncEnvPool ctor (async_envpool.h:88-142) + StateBufferQueue ctor
+ * (state_buffer_queue.h:48-96) + DummyEnv ctor (dummy_envpool.h:125-129).
+ * Allocates the device-resident env state, the StateBuffer ring and the action
+ * staging ring on `device_id`. Fails with EP_ERR_NO_DEVICE when no GPU is
+ * visible. batch_size > num_envs => EP_ERR_INVALID (env_spec.h:74-79). */
+int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out);
+
+/* Replaces: ~AsyncEnvPool (async_envpool.h:144-154). */
+int ep_pool_destroy(ep_pool* pool);
+
+/* Replaces: PyEnvPool::PyReset -> AsyncEnvPool::Reset (py_envpool.h:246-251,
+ * async_envpool.h:176-189). Enqueues a forced reset of `n` envs; results appear
+ * in the StateBuffer ring exactly like a step's. `env_ids` are GLOBAL ids. */
+int ep_pool_reset(ep_pool* pool, const int32_t* env_ids, int32_t n, int32_t mem);
+
+/* Replaces: PyEnvPool::PySend -> AsyncEnvPool::SendImpl (py_envpool.h:219-225,
+ * async_envpool.h:57-80). `arrays[k]` is the k-th action array in
+ * `_action_keys` order (env_spec.h:31-35: env_id, players.env_id, then the
+ * env's own keys), already of the spec dtype and C-contiguous;
+ * `leading_dims[k]` its leading dimension. Non-blocking: the step kernel is
+ * enqueued on the pool's stream and the call returns. Host arrays are fully
+ * consumed (copied to pinned staging) before return; device arrays must stay
+ * untouched until the matching recv. */
+int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
+                 const int64_t* leading_dims, int32_t mem);
+
+/* Replaces: PyEnvPool::PyRecv -> AsyncEnvPool::Recv -> StateBufferQueue::Wait
+ * -> StateBuffer::Wait (py_envpool.h:230-241, async_envpool.h:162-174,
+ * state_buffer_queue.h:139-150, state_buffer.h:135-157). Blocks until the head
+ * batch is complete, then describes it in `out`. EP_MEM_HOST: a fresh host
+ * block holding every array (never reused; free with ep_batch_release).
+ * EP_MEM_DEVICE: views into the ring slot, valid until ring_depth-1 further
+ * batches have been received. Returns EP_ERR_WOULD_BLOCK instead of
+ * deadlocking when fewer than batch_size env-steps are outstanding in async
+ * mode, and EP_ERR_ACTION_CHECK when a step of this batch failed the Dummy
+ * env's action self-check (the batch is still returned). */
+int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
+
+/* Frees the host block of a EP_MEM_HOST batch (the reference frees it when the
+ * numpy capsule dies, py_envpool.h:42-46). No-op for device views. */
+int ep_batch_release(ep_batch* batch);
+
+/* Fused lockstep loop: T consecutive sync-mode send+step rounds of ALL envs in
+ * one kernel launch (the "persistent-kernel step loop" of the north star; the
+ * reference's counterpart is T iterations of envpool.py:135-142 step()).
+ * `arrays[k]` is the k-th action array in `_action_keys` order with an extra
+ * leading step dimension, laid out [T][leading_dims[k]][...] on the device;
+ * `step_stride_rows[k]` is the row stride between consecutive steps (0 = reuse
+ * the same action every step). The T result batches are queued in the ring and
+ * are handed out by the next T ep_pool_recv calls. Requires sync mode
+ * (batch_size == num_envs, max_num_players == 1), no un-received batches and
+ * T <= ring_depth. */
+int ep_pool_rollout(ep_pool* pool, int32_t T, int32_t n_arrays, const void* const* arrays,
+                    const int64_t* leading_dims, const int64_t* step_stride_rows);
+
+/* Wait for everything enqueued on the pool's streams. */
+int ep_pool_sync(ep_pool* pool);
+
+/* Per-episode statistics of the most recently finished episode of every local
+ * env (new: the reference keeps none). fin_return[e] = sum of the
+ * env's rewards over that episode, fin_length[e] = its elapsed_step at done,
+ * ep_count[e] = episodes finished so far. Any pointer may be NULL. */
+int ep_pool_episode_stats(ep_pool* pool, float* fin_return, int32_t* fin_length, int32_t* ep_count,
+                          int32_t mem);
+
+/* Snapshot / restore the whole device-resident env state (new: SURVEY.md §8f-4).
+ * `buf` holds ep_pool_checkpoint_bytes() bytes of host memory. */
+int64_t ep_pool_checkpoint_bytes(ep_pool* pool);
+int ep_pool_checkpoint_save(ep_pool* pool, void* buf);
+int ep_pool_checkpoint_restore(ep_pool* pool, const void* buf);
+
+/* Introspection. */
+int32_t ep_pool_num_envs(ep_pool* pool);
+int32_t ep_pool_batch_size(ep_pool* pool);
+int32_t ep_pool_ring_depth(ep_pool* pool);
+int32_t ep_pool_is_sync(ep_pool* pool);
+void* ep_pool_stream(ep_pool* pool); /* hipStream_t the step kernels run on */
+/* Average device time in microseconds of the step / rollout kernels launched
+ * since the last call with reset != 0 (HIP events on the pool's stream;
+ * recording is enabled by ep_pool_set_timing). */
+int ep_pool_set_timing(ep_pool* pool, int32_t enabled);
+int ep_pool_kernel_time_us(ep_pool* pool, double* total_us, int64_t* launches, int32_t reset);
+
+int32_t ep_device_count(void);
+const char* ep_last_error(void); /* thread-local text of the last failure */
+const char* ep_version(void);
+
+/* ---- YGOPro observation-encode tail --------------------------------------- */
+/* declared in envpool_amd_ygo.h */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVPOOL_AMD_H_ */

@@ -1,0 +1,5 @@
+"""CPU oracle: TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package. The product (envpool_amd) never does.
+"""
