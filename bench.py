@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the Dummy-v0 lockstep reset/step + StateBuffer path.
+
+Workload at N=1 (BASELINE.json configs[1]): Dummy-v0, num_envs=65536, seed=42, sync mode,
+everything resident on one MI355X. A "step" is one lockstep step of ALL envs of a rank:
+65 536 action rows read (env_id + players.env_id + 6-lane list_action), 65 536 env states
+advanced with auto-reset, one full StateBuffer (11 fixed-shape keys) written into the ring.
+
+Timed mode: the fused lockstep loop (`ep_pool_rollout`, T steps per launch, a distinct action
+block per step already resident in HBM, results into a 2T-deep StateBuffer ring and handed out
+by `ep_pool_recv` as device views). The one-launch-per-step mode (`ep_pool_send` +
+`ep_pool_recv`) is measured next to it and reported under "per_step_launch".
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): envs shard by env_id, rank r owns
+global ids [r*65536, (r+1)*65536) (seed_ = seed + GLOBAL id); no data-path collective; every
+rollout the per-episode (return, length) stats are all-gathered over RCCL ("weak" scaling).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_ENVS = 65536
+SEED = 42
+T_FUSED = 64  # lockstep steps per rollout launch
+# Algorithmic bytes per env-step of the step/rollout kernel: 56 B action read
+# (env_id 4 + players.env_id 4 + list_action 48; players.action / players.id are never read by
+# DummyEnv::Step) + 8 B env state read + 8 B write + 71 B StateBuffer row write.
+ALG_BYTES_PER_ENV_STEP = 143
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=2048)
+  ap.add_argument("--warmup", type=int, default=256)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("launch multi-GPU runs with torch.distributed.run --nproc-per-node N")
+    args.gpus = world
+
+  import torch
+  import torch.distributed as dist
+
+  from envpool_amd import capi
+
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  L = capi.lib()
+  N, T = NUM_ENVS, T_FUSED
+  K = max(T, (args.steps + T - 1) // T * T)
+  W = (args.warmup + T - 1) // T * T
+  pool = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=local_rank, env_id_offset=rank * N,
+                         ring_depth=2 * T)
+  h = pool.handle
+
+  # synthetic actions, resident in HBM: a distinct block per step of a rollout
+  env_id = torch.arange(rank * N, (rank + 1) * N, dtype=torch.int32, device=dev)
+  penv = env_id.repeat(T, 1).contiguous()                       # [T, N]
+  la = (torch.arange(T * N, dtype=torch.float64, device=dev) % 997.0).reshape(T, N, 1).repeat(1, 1, 6).contiguous()
+  unused = torch.zeros(N, dtype=torch.int32, device=dev)
+  torch.cuda.synchronize()
+  ptrs = (C.c_void_p * 5)(env_id.data_ptr(), penv.data_ptr(), la.data_ptr(), unused.data_ptr(), unused.data_ptr())
+  dims = (C.c_int64 * 5)(N, N, N, N, N)
+  strides = (C.c_int64 * 5)(0, N, N, 0, 0)
+  batch = capi.Batch()
+  batches = (capi.Batch * T)()
+
+  # episode-stat exchange buffers (multi-GPU only)
+  if world > 1:
+    st_ret = torch.zeros(N, dtype=torch.float32, device=dev)
+    st_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    g_ret = torch.zeros(world * N, dtype=torch.float32, device=dev)
+    g_len = torch.zeros(world * N, dtype=torch.int32, device=dev)
+
+  def check(rc):
+    if rc != 0:
+      raise RuntimeError(L.ep_last_error().decode())
+
+  def recv_T():
+    check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, T, batches))
+
+  def exchange_stats():
+    if world > 1:
+      check(L.ep_pool_episode_stats_async(h, st_ret.data_ptr(), st_len.data_ptr(), None,
+                                          torch.cuda.current_stream().cuda_stream))
+      dist.all_gather_into_tensor(g_ret, st_ret)
+      dist.all_gather_into_tensor(g_len, st_len)
+
+  def run_fused(n_steps):
+    rounds = n_steps // T
+    check(L.ep_pool_rollout(h, T, 5, ptrs, dims, strides))
+    for _ in range(rounds - 1):
+      check(L.ep_pool_rollout(h, T, 5, ptrs, dims, strides))  # next rollout queued ...
+      recv_T()                                                # ... while this one is received
+      exchange_stats()
+    recv_T()
+    exchange_stats()
+    check(L.ep_pool_sync(h))
+
+  # reset all envs (forced reset of every env; sync-mode reset())
+  check(L.ep_pool_reset(h, env_id.data_ptr(), N, capi.EP_MEM_DEVICE))
+  check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
+
+  if W:
+    run_fused(W)
+  check(L.ep_pool_set_timing(h, 1))
+  tot = C.c_double()
+  cnt = C.c_int64()
+  check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+  barrier()
+  t0 = time.perf_counter()
+  run_fused(K)
+  barrier()
+  t1 = time.perf_counter()
+  check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+  check(L.ep_pool_set_timing(h, 0))
+  elapsed = t1 - t0
+  if world > 1:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+  kern_us = tot.value / max(1, cnt.value)  # average rollout-kernel duration (HIP events)
+
+  # one-launch-per-step mode, measured on rank 0's pool the same way (reported, not `value`)
+  per_step = None
+  if True:
+    ks = min(K, 512)
+    la1 = la[0].contiguous()
+    p1 = (C.c_void_p * 5)(env_id.data_ptr(), env_id.data_ptr(), la1.data_ptr(), unused.data_ptr(), unused.data_ptr())
+    torch.cuda.synchronize()
+    for _ in range(16):
+      check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
+    check(L.ep_pool_sync(h))
+    check(L.ep_pool_set_timing(h, 1))
+    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    s0 = time.perf_counter()
+    for _ in range(ks):
+      check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
+    check(L.ep_pool_sync(h))
+    s1 = time.perf_counter()
+    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    check(L.ep_pool_set_timing(h, 0))
+    k1_us = tot.value / max(1, cnt.value)
+    per_step = {
+      "value": N * ks / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / ks * 1e3,
+      "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
+      "note": "ep_pool_send + blocking ep_pool_recv per lockstep step, device-resident actions",
+    }
+
+  cpu = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle.dummy_oracle import DummyOracle
+    o = DummyOracle(num_envs=N, seed=SEED)
+    c0 = time.perf_counter()
+    o.bench_sync(40)
+    rate = 40 / (time.perf_counter() - c0)
+    n_cpu = int(max(100, min(4000, rate * 12.0)))  # ~12 s of CPU work
+    o = DummyOracle(num_envs=N, seed=SEED)
+    c0 = time.perf_counter()
+    o.bench_sync(n_cpu)
+    c1 = time.perf_counter()
+    cpu = {
+      "value": N * n_cpu / (c1 - c0), "unit": "env-steps/s", "cores": 1, "kind": "port",
+      "sample": f"{n_cpu} sync lockstep steps of the same {N}-env workload (reset + send/recv) on "
+                "oracle/dummy_oracle.c, single thread; obs:dyn kept lazy (the reference allocates "
+                "O(N^2) bytes per step there and cannot run this N at all)",
+    }
+
+  if rank == 0:
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+      try:
+        traffic = json.load(open(pmc_path)).get("rollout_hbm_bytes_per_launch")
+      except Exception:
+        traffic = None
+    achieved = ALG_BYTES_PER_ENV_STEP * N * T / (kern_us * 1e-6) / 1e9
+    line = {
+      "metric": "env-steps/sec (whole node) Dummy-v0", "value": world * N * K / elapsed, "unit": "env-steps/s",
+      "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+      "data": "synthetic",
+      "config": {
+        "workload": f"Dummy-v0 num_envs={N} per GPU, seed={SEED}, sync lockstep reset/step, "
+                    f"fused rollout T={T} steps/launch, device-resident actions, StateBuffer ring depth {2 * T}",
+        "global_num_envs": world * N, "sharding": "env_id blocks, one independent pool per GPU",
+        "collective": "RCCL all-gather of episode (return,length) per rollout" if world > 1 else "none",
+      },
+      "roofline": {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel": "dummy_rollout_sp<10>", "kernel_us": kern_us,
+        "alg_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * N * T,
+      },
+      "per_step_launch": per_step,
+    }
+    if cpu is not None:
+      line["cpu_baseline"] = cpu
+    print(json.dumps(line), flush=True)
+
+  pool.close()
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

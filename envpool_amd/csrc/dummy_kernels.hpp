@@ -408,4 +408,15 @@ __global__ __launch_bounds__(kBlock) void dummy_rollout_sp(RolloutArgs a) {
   if (in_range) a.env[local] = rec;
 }
 
+// One consistent copy of the per-env episode statistics, taken between two launches on the
+// step stream (feeds the optional RCCL all-gather; never on the step kernels' critical path).
+__global__ void snapshot_stats(StatPtrs st, int n, float* __restrict__ fin_return,
+                               int32_t* __restrict__ fin_length, int32_t* __restrict__ ep_count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (fin_return) fin_return[i] = st.fin_return[i];
+  if (fin_length) fin_length[i] = st.fin_length[i];
+  if (ep_count) ep_count[i] = st.ep_count[i];
+}
+
 }  // namespace epk

@@ -53,7 +53,8 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
     sh.has_work = true;
-    HIP_TRY(hipEventRecord(sh.ready, p->stream));
+    sh.launch_id = ++p->launch_seq;
+    if (int rc2 = mark_launch(p, sh.launch_id)) return rc2;
     p->alloc_count += cnt;
     i0 += cnt;
   }

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -70,8 +71,8 @@ struct SlotHost {
   uint64_t alloc_count = 0;  // StateBuffer::alloc_count_
   uint32_t shared_off = 0;   // low half of StateBuffer::offsets_
   std::vector<std::pair<int64_t, int64_t>> written;  // shared rows written, [a,b)
-  hipEvent_t ready = nullptr;
   bool has_work = false;
+  uint64_t launch_id = 0;  // id of the last launch that wrote this slot
 };
 
 }  // namespace
@@ -113,6 +114,11 @@ struct ep_pool {
   uint64_t alloc_count = 0, done_ptr = 0;  // StateBufferQueue::alloc_count_/done_ptr_ (in rows / batches)
   int64_t stepping_env_num = 0;            // async_envpool.h:49
   uint64_t recv_seq = 0;
+  std::deque<std::pair<uint64_t, hipEvent_t>> inflight;  // (launch id, completion event)
+  std::vector<hipEvent_t> done_ev_pool;
+  uint64_t launch_seq = 0;       // launches enqueued on `stream`
+  uint64_t completed_launch = 0; // highest launch id known to have finished (stream is in-order)
+  hipEvent_t stats_ev = nullptr, consumer_ev = nullptr;
   std::vector<SlotHost> slots;
   std::mutex mu;
   std::shared_ptr<HostBlocks> blocks;
@@ -216,6 +222,38 @@ int drain_timed(ep_pool* p) {
 // have been received; reference: StateBuffer::Allocate throws once alloc_count_ >= batch_)
 bool slot_free_for(ep_pool* p, uint64_t bi) { return bi < p->done_ptr + (uint64_t)p->Q; }
 
+// Records a completion event for launch `lid` on the step stream.
+int mark_launch(ep_pool* p, uint64_t lid) {
+  hipEvent_t e = nullptr;
+  if (!p->done_ev_pool.empty()) {
+    e = p->done_ev_pool.back();
+    p->done_ev_pool.pop_back();
+  } else {
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventRecord(e, p->stream));
+  p->inflight.emplace_back(lid, e);
+  return EP_OK;
+}
+
+// Blocks until launch `lid` has finished (the stream is in-order, so everything older has too).
+int wait_launch(ep_pool* p, uint64_t lid) {
+  if (lid <= p->completed_launch) return EP_OK;
+  while (!p->inflight.empty() && p->inflight.front().first < lid) {
+    p->done_ev_pool.push_back(p->inflight.front().second);  // older launch: done once `lid` is
+    p->inflight.pop_front();
+  }
+  if (!p->inflight.empty() && p->inflight.front().first == lid) {
+    HIP_TRY(hipEventSynchronize(p->inflight.front().second));
+    p->done_ev_pool.push_back(p->inflight.front().second);
+    p->inflight.pop_front();
+  } else {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  p->completed_launch = lid;
+  return EP_OK;
+}
+
 // Launch the single-player kernel for items [i0, i0+n) of one send/reset that land in `slot`
 // at rows row0...
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
@@ -280,7 +318,8 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
     sh.has_work = true;
-    HIP_TRY(hipEventRecord(sh.ready, p->stream));
+    sh.launch_id = ++p->launch_seq;
+    if (int rc2 = mark_launch(p, sh.launch_id)) return rc2;
     p->alloc_count += cnt;
     i0 += cnt;
   }
@@ -434,7 +473,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     HIP_TRY(hipEventCreateWithFlags(&p->stage_copied[a], hipEventDisableTiming));
   }
   p->slots.resize(p->Q);
-  for (auto& s : p->slots) HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
   p->blocks = std::make_shared<HostBlocks>();
   p->blocks->bytes = p->slot_stride;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -449,7 +489,10 @@ int ep_pool_destroy(ep_pool* p) {
   (void)hipStreamSynchronize(p->copy_stream);
   for (auto& ab : p->timed) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
-  for (auto& s : p->slots) if (s.ready) (void)hipEventDestroy(s.ready);
+  for (auto& fe : p->inflight) (void)hipEventDestroy(fe.second);
+  for (auto e : p->done_ev_pool) (void)hipEventDestroy(e);
+  if (p->stats_ev) (void)hipEventDestroy(p->stats_ev);
+  if (p->consumer_ev) (void)hipEventDestroy(p->consumer_ev);
   for (auto e : p->stage_free) (void)hipEventDestroy(e);
   for (auto e : p->stage_copied) (void)hipEventDestroy(e);
   (void)hipFree(p->d_ring);
@@ -555,8 +598,14 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
                 (long long)leading_dims[0], (long long)leading_dims[1], (long long)leading_dims[2]);
   if (step_stride_rows[0] != 0)
     return fail(EP_ERR_INVALID, "rollout keeps the env_id array fixed across steps (step stride 0)");
-  if (p->alloc_count != p->done_ptr * (uint64_t)p->B || p->stepping_env_num != 0)
-    return fail(EP_ERR_INVALID, "rollout needs an empty queue: receive outstanding batches first");
+  if (p->alloc_count % (uint64_t)p->B != 0)
+    return fail(EP_ERR_INVALID, "rollout needs the queue on a batch boundary: receive the partial batch first");
+  {
+    uint64_t bi = p->alloc_count / (uint64_t)p->B;
+    if (!slot_free_for(p, bi + (uint64_t)T - 1))
+      return fail(EP_ERR_RING_FULL, "rollout of %d steps does not fit: %llu un-received batches in a ring of %d",
+                  T, (unsigned long long)(bi - p->done_ptr), p->Q);
+  }
   epk::RolloutArgs a;
   a.env_id = (const int32_t*)arrays[0];
   a.players_env_id = (const int32_t*)arrays[1];
@@ -583,6 +632,7 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
       hipLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, a);
   }
   HIP_TRY(hipGetLastError());
+  const uint64_t lid = ++p->launch_seq;
   for (int t = 0; t < T; ++t) {
     int slot = (int)((bi0 + (uint64_t)t) % (uint64_t)p->Q);
     SlotHost& sh = p->slots[slot];
@@ -590,18 +640,19 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
     sh.shared_off += p->B;
     sh.written.emplace_back(0, p->B);
     sh.has_work = true;
-    HIP_TRY(hipEventRecord(sh.ready, p->stream));
+    sh.launch_id = lid;
   }
+  if (int rc2 = mark_launch(p, lid)) return rc2;
   p->alloc_count += (uint64_t)T * (uint64_t)p->B;
   p->stepping_env_num += (int64_t)T * p->B;
   return EP_OK;
 }
 
-int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
-  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+}  // extern "C"
+
+namespace {
+int recv_locked(ep_pool* p, int32_t mem, ep_batch* out) {
+  int rc = EP_OK;
   const int slot = (int)(p->done_ptr % (uint64_t)p->Q);
   SlotHost& sh = p->slots[slot];
   // async_envpool.h:163-166
@@ -614,7 +665,8 @@ int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
                 (unsigned long long)sh.alloc_count, p->B);
   const uint32_t nrows = sh.shared_off;
   uint32_t nplayers = nrows;
-  if (sh.has_work) HIP_TRY(hipEventSynchronize(sh.ready));
+  if (sh.has_work)
+    if ((rc = wait_launch(p, sh.launch_id))) return rc;
   if (p->P > 1) {
     HIP_TRY(hipMemcpyAsync(p->h_slot_players + slot, p->d_slot_players + slot, 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemsetAsync(p->d_slot_players + slot, 0, 4, p->stream));
@@ -712,6 +764,49 @@ int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
   sh.has_work = false;
   if (p->is_sync) p->stepping_env_num -= nrows;
   return status;
+}
+}  // namespace
+
+extern "C" {
+
+int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  return recv_locked(p, mem, out);
+}
+
+int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
+  if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  int status = EP_OK;
+  for (int i = 0; i < n; ++i) {
+    rc = recv_locked(p, mem, out + i);
+    if (rc == EP_ERR_ACTION_CHECK) { status = rc; continue; }
+    if (rc != EP_OK) return rc;
+  }
+  return status;
+}
+
+int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_length, int32_t* ep_count,
+                                void* consumer_stream) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  hipStream_t cs = (hipStream_t)consumer_stream;
+  // destination buffers may still be read by the consumer's previous work (e.g. an all-gather)
+  HIP_TRY(hipEventRecord(p->consumer_ev, cs));
+  HIP_TRY(hipStreamWaitEvent(p->stream, p->consumer_ev, 0));
+  hipLaunchKernelGGL(epk::snapshot_stats, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->stats, p->N,
+                     fin_return, fin_length, ep_count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(p->stats_ev, p->stream));
+  HIP_TRY(hipStreamWaitEvent(cs, p->stats_ev, 0));
+  return EP_OK;
 }
 
 int ep_batch_release(ep_batch* b) {

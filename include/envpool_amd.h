@@ -143,6 +143,10 @@ int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
  * env's action self-check (the batch is still returned). */
 int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
 
+/* `n` consecutive ep_pool_recv calls in one (the natural companion of
+ * ep_pool_rollout). `out` points at n ep_batch structs. */
+int ep_pool_recv_many(ep_pool* pool, int32_t mem, int32_t n, ep_batch* out);
+
 /* Frees the host block of a EP_MEM_HOST batch (the reference frees it when the
  * numpy capsule dies, py_envpool.h:42-46). No-op for device views. */
 int ep_batch_release(ep_batch* batch);
@@ -155,8 +159,9 @@ int ep_batch_release(ep_batch* batch);
  * `step_stride_rows[k]` is the row stride between consecutive steps (0 = reuse
  * the same action every step). The T result batches are queued in the ring and
  * are handed out by the next T ep_pool_recv calls. Requires sync mode
- * (batch_size == num_envs, max_num_players == 1), no un-received batches and
- * T <= ring_depth. */
+ * (batch_size == num_envs, max_num_players == 1), the queue on a batch boundary
+ * and T free ring slots (so with ring_depth >= 2T the next rollout can be
+ * enqueued while the previous one's batches are still being received). */
 int ep_pool_rollout(ep_pool* pool, int32_t T, int32_t n_arrays, const void* const* arrays,
                     const int64_t* leading_dims, const int64_t* step_stride_rows);
 
@@ -169,6 +174,13 @@ int ep_pool_sync(ep_pool* pool);
  * ep_count[e] = episodes finished so far. Any pointer may be NULL. */
 int ep_pool_episode_stats(ep_pool* pool, float* fin_return, int32_t* fin_length, int32_t* ep_count,
                           int32_t mem);
+
+/* Stream-ordered variant for device consumers (the RCCL all-gather of the
+ * multi-GPU bench): a snapshot kernel is enqueued behind the pool's pending
+ * launches, writes into the given DEVICE buffers, and `consumer_stream`
+ * (a hipStream_t) is made to wait for it. No host synchronisation. */
+int ep_pool_episode_stats_async(ep_pool* pool, float* fin_return, int32_t* fin_length,
+                                int32_t* ep_count, void* consumer_stream);
 
 /* Snapshot / restore the whole device-resident env state (new: SURVEY.md §8f-4).
  * `buf` holds ep_pool_checkpoint_bytes() bytes of host memory. */
