@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 NUM_ENVS = 65536
 SEED = 42
-T_FUSED = 64  # lockstep steps per rollout launch
+T_FUSED = int(os.environ.get("EP_BENCH_T", "64"))  # lockstep steps per rollout launch
 # Algorithmic bytes per env-step of the step/rollout kernel: 56 B action read
 # (env_id 4 + players.env_id 4 + list_action 48; players.action / players.id are never read by
 # DummyEnv::Step) + 8 B env state read + 8 B write + 71 B StateBuffer row write.
@@ -125,7 +125,7 @@ def main():
 
   if W:
     run_fused(W)
-  check(L.ep_pool_set_timing(h, 1))
+  check(L.ep_pool_set_timing(h, 0 if os.environ.get("EP_BENCH_NO_EVENTS") else 1))
   tot = C.c_double()
   cnt = C.c_int64()
   check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
@@ -178,7 +178,7 @@ def main():
     c0 = time.perf_counter()
     o.bench_sync(40)
     rate = 40 / (time.perf_counter() - c0)
-    n_cpu = int(max(100, min(4000, rate * 12.0)))  # ~12 s of CPU work
+    n_cpu = int(max(100, min(40000, rate * 12.0)))  # ~12 s of CPU work
     o = DummyOracle(num_envs=N, seed=SEED)
     c0 = time.perf_counter()
     o.bench_sync(n_cpu)
@@ -213,7 +213,7 @@ def main():
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "kernel": "dummy_rollout_sp<10>", "kernel_us": kern_us,
+        "kernel": "dummy_rollout_dma<4>", "kernel_us": kern_us,
         "alg_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * N * T,
       },
       "per_step_launch": per_step,

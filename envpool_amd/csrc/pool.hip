@@ -28,6 +28,7 @@
 #include "../../include/envpool_amd.h"
 #include "dummy_kernels.hpp"
 #include "dummy_mp_kernels.hpp"
+#include "dummy_rollout_wave.hpp"
 
 namespace {
 
@@ -122,6 +123,8 @@ struct ep_pool {
   std::vector<SlotHost> slots;
   std::mutex mu;
   std::shared_ptr<HostBlocks> blocks;
+  int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
+  bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -405,6 +408,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->Q = cfg->ring_depth > 0 ? cfg->ring_depth : ref_depth;
   if (p->Q < 2) return fail(EP_ERR_INVALID, "ring_depth must be >= 2");
   p->device = cfg->device_id;
+  if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
+  if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -623,13 +628,27 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
   a.err = p->d_err + a.slot0;  // errors of the whole rollout are reported with its first batch
   a.pc = pool_const(p);
   a.T = T;
-  dim3 grid((p->N + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
   {
     TimedScope ts(p);
-    if (p->S == 10)
-      hipLaunchKernelGGL(epk::dummy_rollout_sp<10>, grid, block, 0, p->stream, a);
-    else
-      hipLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, a);
+    if (p->S == 10 && p->N % epk::kWave == 0 && !p->force_generic) {
+      // wave-autonomous software-pipelined loop (dummy_rollout_wave.hpp)
+      const dim3 g(p->N / epk::kWave), b(epk::kWave);
+      if (p->rollout_variant == 1) {
+        if (T % 4 == 0) hipLaunchKernelGGL(epk::dummy_rollout_wave<4>, g, b, 0, p->stream, a);
+        else if (T % 2 == 0) hipLaunchKernelGGL(epk::dummy_rollout_wave<2>, g, b, 0, p->stream, a);
+        else hipLaunchKernelGGL(epk::dummy_rollout_wave<1>, g, b, 0, p->stream, a);
+      } else if (p->rollout_variant == 2) {
+        hipLaunchKernelGGL(epk::dummy_rollout_dma<4>, g, b, 0, p->stream, a);
+      } else {
+        hipLaunchKernelGGL(epk::dummy_rollout_dma<6>, g, b, 0, p->stream, a);
+      }
+    } else {
+      dim3 grid((p->N + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
+      if (p->S == 10)
+        hipLaunchKernelGGL(epk::dummy_rollout_sp<10>, grid, block, 0, p->stream, a);
+      else
+        hipLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, a);
+    }
   }
   HIP_TRY(hipGetLastError());
   const uint64_t lid = ++p->launch_seq;
