@@ -27,11 +27,16 @@ sys.path.insert(0, ROOT)
 
 NUM_ENVS = 65536
 SEED = 42
-T_FUSED = int(os.environ.get("EP_BENCH_T", "64"))  # lockstep steps per rollout launch
-# Algorithmic bytes per env-step of the step/rollout kernel: 56 B action read
+T_FUSED = int(os.environ.get("EP_BENCH_T", "128"))  # lockstep steps per rollout launch
+# Algorithmic bytes. One-launch-per-step kernel, per env-step: 56 B action read
 # (env_id 4 + players.env_id 4 + list_action 48; players.action / players.id are never read by
-# DummyEnv::Step) + 8 B env state read + 8 B write + 71 B StateBuffer row write.
+# DummyEnv::Step) + 8 B env state read + 8 B write + 71 B StateBuffer row write = 143 B.
+# Fused rollout kernel: env_id and the env state stay in registers for the T steps of a launch,
+# so per env-step only 52 B (players.env_id + list_action) + 71 B = 123 B move, plus 20 B per
+# env per launch (env_id 4 + state 8 read, state 8 write).
 ALG_BYTES_PER_ENV_STEP = 143
+ALG_ROLLOUT_PER_ENV_STEP = 123
+ALG_ROLLOUT_PER_ENV_LAUNCH = 20
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -195,10 +200,12 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
       try:
-        traffic = json.load(open(pmc_path)).get("rollout_hbm_bytes_per_launch")
+        # measured with rocprofv3 --pmc at T=64 (profiles/): bytes scale with the steps per launch
+        traffic = json.load(open(pmc_path))["rollout_hbm_bytes_per_env_step"] * N * T
       except Exception:
         traffic = None
-    achieved = ALG_BYTES_PER_ENV_STEP * N * T / (kern_us * 1e-6) / 1e9
+    alg_launch = N * (T * ALG_ROLLOUT_PER_ENV_STEP + ALG_ROLLOUT_PER_ENV_LAUNCH)
+    achieved = alg_launch / (kern_us * 1e-6) / 1e9
     line = {
       "metric": "env-steps/sec (whole node) Dummy-v0", "value": world * N * K / elapsed, "unit": "env-steps/s",
       "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -214,7 +221,7 @@ def main():
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel": "dummy_rollout_dma<4>", "kernel_us": kern_us,
-        "alg_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * N * T,
+        "alg_bytes_per_launch": alg_launch,
       },
       "per_step_launch": per_step,
     }
