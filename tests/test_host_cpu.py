@@ -1,0 +1,230 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares; the pybind spec
+surface matches the reference's; host front-end logic; no-GPU failure
+is loud; the N>1 sharding path under gloo with world_size 2."""
+import ctypes
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "dummy_survey_traces.json")))["spec"]
+
+
+def _declared_symbols():
+  names = []
+  for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+    text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+    names += re.findall(r"\b(ep_[a-z0-9_]+)\s*\(", text)
+  return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+  from envpool_amd._loader import load_library
+  lib = load_library()
+  syms = _declared_symbols()
+  assert len(syms) >= 20
+  for s in syms:
+    assert hasattr(lib, s), f"libenvpool_amd.so does not export {s}"
+
+
+def test_capi_binding_matches_header():
+  from envpool_amd import capi
+  declared = set(_declared_symbols())
+  assert set(capi.SYMBOLS) <= declared
+  L = capi.lib()
+  assert b"gfx950" in L.ep_version()
+
+
+def test_no_gpu_fails_loudly():
+  from envpool_amd import capi
+  L = capi.lib()
+  if L.ep_device_count() > 0:
+    pytest.skip("a GPU is visible")
+  with pytest.raises(capi.EpError) as e:
+    capi.DummyPoolC(num_envs=8)
+  assert e.value.code == capi.EP_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_invalid_configs_rejected_before_touching_a_device():
+  from envpool_amd import capi
+  with pytest.raises(capi.EpError) as e:
+    capi.DummyPoolC(num_envs=4, batch_size=8)
+  assert e.value.code == capi.EP_ERR_INVALID and "batch_size <= num_envs" in str(e.value)
+  with pytest.raises(capi.EpError):
+    capi.DummyPoolC(num_envs=0)
+
+
+def test_spec_surface_matches_reference():
+  from envpool_amd.dummy.dummy_envpool import _DummyEnvPool, _DummyEnvSpec
+  assert type(_DummyEnvSpec).__name__ == "ABCMeta" and type(_DummyEnvPool).__name__ == "ABCMeta"
+  assert list(_DummyEnvSpec._config_keys)[:11] == GOLD["config_keys"]
+  assert list(_DummyEnvSpec._default_config_values)[:11] == GOLD["default_config_values"]
+  assert list(_DummyEnvSpec._state_keys) == GOLD["state_keys"] == list(_DummyEnvPool._state_keys)
+  assert list(_DummyEnvSpec._action_keys) == GOLD["action_keys"] == list(_DummyEnvPool._action_keys)
+  s = _DummyEnvSpec((8, 0, 0, 1, -1, "envpool2", 42, False, 2**31 - 1, 10, 6))  # the reference's 11-tuple
+  assert s._config_values[1] == 8  # batch_size 0 -> num_envs (env_spec.h:80-82)
+  st = dict(zip(s._state_keys, s._state_spec))
+  i32, f32 = np.dtype(np.int32), np.dtype(np.float32)
+  assert st["info:env_id"] == (i32, [], (-2**31, 2**31 - 1), ([], []))
+  assert st["reward"] == (f32, [-1], (GOLD["float_min"], float(np.finfo(np.float32).max)), ([], []))
+  assert st["discount"][2] == (0.0, 1.0)
+  assert st["done"] == (np.dtype(bool), [], (False, True), ([], []))
+  assert st["obs:raw"][:2] == (i32, [-1, 10])
+  assert st["obs:dyn"][:2] == (i32, ([-1], [-1, 10]))
+  assert st["info:players.id"][2] == (0, 1)
+  ac = dict(zip(s._action_keys, s._action_spec))
+  assert ac["list_action"] == (np.dtype(np.float64), [6], (GOLD["double_min"], float(np.finfo(np.float64).max)), ([], []))
+  with pytest.raises(ValueError, match="batch_size <= num_envs"):
+    _DummyEnvSpec((4, 8, 0, 1, -1, "x", 42, False, 100, 10, 6))
+
+
+def test_make_spec_and_registry_checks():
+  import envpool_amd
+  assert "Dummy-v0" in envpool_amd.list_all_envs()
+  spec = envpool_amd.make_spec("Dummy-v0", num_envs=16, batch_size=4, seed=7, state_num=12)
+  assert spec.config.num_envs == 16 and spec.config.batch_size == 4 and spec.config.state_num == 12
+  assert spec.state_array_spec["obs:raw"].shape == [-1, 12]
+  assert spec.action_array_spec["list_action"].dtype == np.float64
+  with pytest.raises(AssertionError):
+    envpool_amd.make_spec("Dummy-v0", num_envs=4, batch_size=5)
+  with pytest.raises(AssertionError):
+    envpool_amd.make_spec("Dummy-v0", num_envs=4, seed=2**31)
+  with pytest.raises(ValueError, match="gym_reset_return_info"):
+    envpool_amd.make("Dummy-v0", "gym", num_envs=2, gym_reset_return_info=False)
+
+
+class _FakeRaw:
+  """Stands in for the pybind pool: records what the front-end hands to _send/_reset."""
+  _state_keys = GOLD["state_keys"]
+  _action_keys = GOLD["action_keys"]
+
+  def __init__(self, spec):
+    self._spec = spec
+    self.sent, self.reset_ids = [], []
+
+  def _send(self, arrays):
+    self.sent.append(arrays)
+
+  def _reset(self, ids):
+    self.reset_ids.append(ids)
+
+  def _recv(self):
+    n = 3
+    z = np.zeros(n, np.int32)
+    return [np.arange(n, dtype=np.int32), z, z + 5, np.array([True, True, False]), np.zeros(n, np.float32),
+            np.ones(n, np.float32), z, np.array([True, False, False]), np.zeros((n, 10), np.int32), None,
+            np.zeros(n, bool), z]
+
+
+def _front(kind):
+  import envpool_amd
+  from envpool_amd.python import pool as P
+  spec = envpool_amd.make_spec("Dummy-v0", num_envs=3, gym_reset_return_info=True)
+  front = {"raw": P.EnvPoolFrontEnd, "gym": P.GymFrontEnd, "gymnasium": P.GymnasiumFrontEnd, "dm": P.DMFrontEnd}[kind]
+  return type("T", (front, _FakeRaw), {})(spec)
+
+
+def test_front_end_action_marshalling():
+  env = _front("raw")
+  la = np.full((3, 6), 2.0)
+  env.send({"list_action": la, "players": {"action": np.zeros(3, np.int32), "id": np.zeros(3, np.int32)}})
+  a = env.sent[-1]
+  assert [x.dtype for x in a] == [np.int32, np.int32, np.float64, np.int32, np.int32]
+  assert a[0].tolist() == [0, 1, 2] and a[1] is a[0]  # env_id defaults to all ids, players.env_id to env_id
+  env.send({"list_action": la[:2], "players.action": np.zeros(2, np.int32), "players.id": np.zeros(2, np.int32)},
+           env_id=np.array([2, 0]))
+  assert env.sent[-1][0].tolist() == [2, 0] and env.sent[-1][0].dtype == np.int32
+  env2 = _front("raw")
+  with pytest.raises(RuntimeError, match="Expected dtype"):
+    env2.send({"list_action": la.astype(np.float32), "players.action": np.zeros(3, np.int32), "players.id": np.zeros(3, np.int32)})
+  assert env.config["num_envs"] == 3 and len(env) == 3 and not env.is_async
+
+
+@pytest.mark.parametrize("kind", ["raw", "gym", "gymnasium"])
+def test_front_end_step_output(kind):
+  env = _front(kind)
+  obs, rew, term, trunc, info = env.step({"list_action": np.zeros((3, 6)), "players.action": np.zeros(3, np.int32),
+                                          "players.id": np.zeros(3, np.int32)})
+  assert set(obs) == {"raw", "dyn"} and obs["raw"].shape == (3, 10)
+  assert term.tolist() == [False, True, False] and trunc.tolist() == [True, False, False]  # done & ~trunc
+  assert info["env_id"].tolist() == [0, 1, 2] and set(info["players"]) == {"env_id", "done", "id"}
+  assert info["elapsed_step"].tolist() == [5, 5, 5]
+  obs, info = env.reset()
+  assert env.reset_ids[-1].tolist() == [0, 1, 2] and "elapsed_step" in info
+
+
+def test_front_end_dm_timestep():
+  ts = _front("dm").step({"list_action": np.zeros((3, 6)), "players.action": np.zeros(3, np.int32),
+                          "players.id": np.zeros(3, np.int32)})
+  assert ts.step_type.tolist() == [0, 0, 0] and ts.first().all()
+  assert ts.observation.raw.shape == (3, 10) and ts.observation.players.env_id.shape == (3,)
+  assert ts.observation.env_id.tolist() == [0, 1, 2]
+
+
+def test_lazy_dyn():
+  from envpool_amd.python.lazy import LazyDyn
+  d = LazyDyn(np.array([0, 2, 70000], np.int32), 10)
+  assert len(d) == 3 and d[1].shape == (3, 10) and (d[1] == 2).all() and d[1].dtype == np.int32
+  assert d[2].shape == (70001, 10)
+  m = LazyDyn(np.array([1, 0], np.int32), 4).materialize()
+  assert m.dtype == object and m[0].shape == (2, 4) and m[1].tolist() == [[0, 0, 0, 0]]
+
+
+def test_shard_helpers():
+  from envpool_amd.shard import owner_of, shard_range, split_by_owner
+  assert shard_range(3, 8, 524288) == (196608, 65536)
+  with pytest.raises(ValueError):
+    shard_range(0, 3, 8)
+  r, l = owner_of(np.array([0, 65535, 65536, 524287]), 8, 524288)
+  assert r.tolist() == [0, 0, 1, 7] and l.tolist() == [0, 65535, 0, 65535]
+  parts = split_by_owner([5, 0, 7, 2], 2, 8)
+  assert parts[0].tolist() == [1, 3] and parts[1].tolist() == [0, 2]
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["EP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from envpool_amd.shard import shard_range, all_gather_episode_stats
+from oracle.dummy_oracle import DummyOracle
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+G, seed, steps = 16, 2, 40
+off, n = shard_range(rank, world, G)
+o = DummyOracle(num_envs=n, seed=seed, env_id_offset=off)
+ids = np.arange(off, off + n, dtype=np.int32)
+la = np.full((n, 6), 1.5); z = np.zeros(n, np.int32)
+o._reset(ids); o._recv()
+fin_len = np.zeros(n, np.int32); fin_ret = np.zeros(n, np.float32); acc = np.zeros(n, np.float32)
+for t in range(steps):
+  o._send([ids, ids, la, z, z]); r = o._recv()
+  acc = np.where(r[2] == 0, 0, acc) + r[4]
+  fin_len = np.where(r[3], r[2], fin_len); fin_ret = np.where(r[3], acc, fin_ret)
+g_ret, g_len = all_gather_episode_stats(torch.from_numpy(fin_ret), torch.from_numpy(fin_len))
+# every rank must hold the stats of the whole pool, ordered by global env_id
+L = np.maximum(1, seed + np.arange(G))
+want = np.where(L <= steps, L, 0)
+assert g_len.numpy().tolist() == want.tolist(), (g_len, want)
+assert g_ret.numpy().tolist() == [0.0] * G
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_stats_all_gather_gloo_world2(tmp_path):
+  """N>1 path on CPU: two ranks own env_id blocks, step their shards, and all-gather the
+  episode stats (gloo stands in for RCCL)."""
+  script = tmp_path / "worker.py"
+  script.write_text(_GLOO_WORKER)
+  env = dict(os.environ, EP_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+  out = subprocess.run(
+    [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+     "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=240)
+  assert out.returncode == 0, out.stdout + out.stderr
+  assert out.stdout.count("ok") == 2
