@@ -128,3 +128,150 @@ def test_rollout_reports_action_check():
   assert g.last_status == capi.EP_ERR_ACTION_CHECK
   for _ in range(T - 1):
     g._recv()
+
+
+def test_async_mode_fifo_batches():
+  """batch_size < num_envs: rows follow the send order (the reference's arrival order with one
+  worker); batches straddle sends; recv reports would-block instead of deadlocking."""
+  from envpool_amd import capi
+  rng = np.random.default_rng(3)
+  g, o = _pair(num_envs=64, batch_size=24, seed=4)
+  ids = np.arange(64, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  outstanding = 64
+  for it in range(60):
+    while outstanding >= 24:
+      assert_batches_equal(g._recv(), o._recv(), f"it {it}")
+      outstanding -= 24
+    with pytest.raises(capi.EpError) as e:
+      g._recv()
+    assert e.value.code == capi.EP_ERR_WOULD_BLOCK
+    k = int(rng.integers(1, 40))
+    sel = rng.choice(64, size=k, replace=False).astype(np.int32)
+    a = dummy_action(sel)
+    g._send(a); o._send(a)
+    outstanding += k
+
+
+def test_sync_partial_and_quirks():
+  g, o = _pair(num_envs=8, seed=5)
+  ids = np.arange(8, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  assert_batches_equal(g._recv(), o._recv(), "reset")
+  for sel in ([5, 1, 6], list(range(8)), [7], [2, 3, 4, 0]):
+    a = dummy_action(np.array(sel, np.int32))
+    g._send(a); o._send(a)
+    assert_batches_equal(g._recv(), o._recv(), f"partial {sel}")
+  # forced reset of a subset mid-episode
+  g._reset(ids[[3, 0]]); o._reset(ids[[3, 0]])
+  assert_batches_equal(g._recv(), o._recv(), "subset reset")
+  # two partial sends, one recv: same rows, the tail rows must read as zero
+  for sel in ([0, 1, 2], [3, 4, 5]):
+    a = dummy_action(np.array(sel, np.int32))
+    g._send(a); o._send(a)
+  assert_batches_equal(g._recv(), o._recv(), "two sends one recv")
+  # 5 + 5 of 8: the second send straddles two StateBuffers
+  for sel in ([0, 1, 2, 3, 4], [5, 6, 7, 0, 1]):
+    a = dummy_action(np.array(sel, np.int32))
+    g._send(a); o._send(a)
+  assert_batches_equal(g._recv(), o._recv(), "straddle 1")
+  assert_batches_equal(g._recv(), o._recv(), "straddle 2")
+  # recv with nothing outstanding returns an empty batch
+  assert_batches_equal(g._recv(), o._recv(), "empty")
+
+
+def test_trunc_seed_clamp_mismatch_and_state_num():
+  for kw in (dict(num_envs=16, seed=1, max_episode_steps=3), dict(num_envs=8, seed=-5),
+             dict(num_envs=33, seed=0, max_episode_steps=1, state_num=7), dict(num_envs=70, seed=2, state_num=3)):
+    g, o = _pair(**kw)
+    n = kw["num_envs"]
+    ids = np.arange(n, dtype=np.int32)
+    g._reset(ids); o._reset(ids)
+    assert_batches_equal(g._recv(), o._recv(), f"{kw} reset")
+    for t in range(20):
+      pe = ids.copy()
+      pe[t % n] = -1  # players.env_id != env_id -> obs:raw[:,1] = 0 for that row
+      a = dummy_action(ids, players_env_id=pe)
+      g._send(a); o._send(a)
+      assert_batches_equal(g._recv(), o._recv(), f"{kw} t={t}")
+
+
+def test_sharded_pool_uses_global_ids():
+  g, o = _pair(num_envs=256, seed=42, env_id_offset=65536 * 3)
+  ids = np.arange(256, dtype=np.int32) + 65536 * 3
+  g._reset(ids); o._reset(ids)
+  assert_batches_equal(g._recv(), o._recv(), "reset")
+  for t in range(5):
+    a = dummy_action(ids)
+    g._send(a); o._send(a)
+    assert_batches_equal(g._recv(), o._recv(), f"t={t}")
+  from envpool_amd import capi
+  with pytest.raises(capi.EpError) as e:
+    g._send(dummy_action(ids - 1))
+  assert e.value.code == capi.EP_ERR_INVALID
+
+
+def test_ring_full_and_action_check():
+  from envpool_amd import capi
+  g, o = _pair(num_envs=2, seed=3)
+  ids = np.arange(2, dtype=np.int32)
+  for _ in range(o.queue_size):
+    g._send(dummy_action(ids)); assert o._send(dummy_action(ids)) == 0
+  with pytest.raises(capi.EpError) as e:
+    g._send(dummy_action(ids))
+  assert e.value.code == capi.EP_ERR_RING_FULL and o._send(dummy_action(ids)) == 5
+  g2, _ = _pair(num_envs=4, seed=9)
+  g2._reset(np.arange(4, dtype=np.int32)); g2._recv()
+  a = dummy_action(np.arange(4, dtype=np.int32))
+  a[2][1, 4] = 7.0
+  g2._send(a)
+  g2._recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+  assert g2.last_status == capi.EP_ERR_ACTION_CHECK
+
+
+@pytest.mark.parametrize("P,n,B", [(3, 4, 0), (2, 16, 0), (4, 300, 0), (3, 40, 16), (5, 2000, 512)])
+def test_multiplayer_ragged_player_dim(P, n, B):
+  """max_num_players > 1: player rows are a device prefix sum."""
+  g, o = _pair(num_envs=n, batch_size=B, max_num_players=P, seed=2)
+  ids = np.arange(n, dtype=np.int32)
+  bsz = B or n
+  g._reset(ids); o._reset(ids)
+  outstanding, last_pe = n, {}
+  rng = np.random.default_rng(P)
+  for it in range(25):
+    got_ids = []
+    while outstanding >= bsz:
+      gr, orr = g._recv(), o._recv()
+      assert_batches_equal(gr, orr, f"P={P} it={it}")
+      got_ids.append(orr[1])
+      outstanding -= bsz
+    # send back every env we have seen, with one action row per player it reported
+    pe = np.concatenate(got_ids) if got_ids else np.zeros(0, np.int32)
+    sel = np.unique(pe) if pe.size else ids[:0]
+    if sel.size == 0:
+      sel = ids[: bsz - outstanding]; pe = sel
+    perm = rng.permutation(sel.size)
+    sel = sel[perm].astype(np.int32)
+    a = dummy_action(sel, players_env_id=pe)
+    g._send(a); o._send(a)
+    outstanding += sel.size
+
+
+def test_checkpoint_roundtrip():
+  import ctypes as C
+  from envpool_amd import capi
+  g, o = _pair(num_envs=100, seed=3)
+  L = capi.lib()
+  ids = np.arange(100, dtype=np.int32)
+  g._reset(ids); o._reset(ids); g._recv(); o._recv()
+  for _ in range(7):
+    g._send(dummy_action(ids)); o._send(dummy_action(ids)); g._recv(); o._recv()
+  nbytes = L.ep_pool_checkpoint_bytes(g.handle)
+  buf = C.create_string_buffer(nbytes)
+  capi._check(L.ep_pool_checkpoint_save(g.handle, buf))
+  want = []
+  for _ in range(9):
+    g._send(dummy_action(ids)); o._send(dummy_action(ids)); want.append(o._recv()); assert_batches_equal(g._recv(), want[-1])
+  capi._check(L.ep_pool_checkpoint_restore(g.handle, buf))
+  for w in want:
+    g._send(dummy_action(ids)); assert_batches_equal(g._recv(), w, "after restore")

@@ -1,0 +1,100 @@
+"""GPU: the drop-in Python surface — envpool_amd.make(...) -> reset/step/send/recv — against the
+oracle, plus the raw pybind `_DummyEnvPool` boundary (py_envpool.h:279-287)."""
+import numpy as np
+import pytest
+
+from tests.util import assert_batches_equal, dummy_action
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raw_pybind_boundary_config1():
+  """BASELINE config 1 shape (sync, N=8, B=8, seed 42) through _reset/_send/_recv, including the
+  obs:dyn object array of arrays."""
+  from envpool_amd.dummy.dummy_envpool import _DummyEnvPool, _DummyEnvSpec
+  from oracle.dummy_oracle import DummyOracle
+  spec = _DummyEnvSpec((8, 8, 0, 1, -1, "envpool2", 42, False, 2**31 - 1, 10, 6))
+  pool, o = _DummyEnvPool(spec), DummyOracle(num_envs=8, seed=42)
+  ids = np.arange(8, dtype=np.int32)
+  pool._reset(ids); o._reset(ids)
+  for t in range(60):
+    got, want = pool._recv(), o._recv(dyn="eager")
+    assert len(got) == 12
+    assert_batches_equal(got, want, f"t={t}")
+    dyn = got[9]
+    assert dyn.dtype == object and dyn.shape == (8,)
+    for e in range(8):
+      assert dyn[e].dtype == np.int32 and np.array_equal(dyn[e], want[9][e])
+    a = dummy_action(ids, value=1.5)
+    # force-cast like the reference (py_envpool.h:81,90): float32 list_action, int64 ids
+    pool._send([a[0].astype(np.int64), a[1], a[2].astype(np.float32), a[3], a[4]])
+    o._send(a)
+  kept = pool._recv()  # returned buffers stay valid after the pool is gone
+  snapshot = [np.array(x) for k, x in enumerate(kept) if k != 9]
+  del pool
+  for x, y in zip([x for k, x in enumerate(kept) if k != 9], snapshot):
+    assert np.array_equal(x, y)
+
+
+def test_make_step_reset():
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=32, seed=3)
+  o = DummyOracle(num_envs=32, seed=3)
+  ids = np.arange(32, dtype=np.int32)
+  obs, info = env.reset()
+  o._reset(ids); w = o._recv()
+  assert np.array_equal(obs["raw"], w[8]) and np.array_equal(info["env_id"], w[0])
+  act = {"list_action": np.full((32, 6), 0.5), "players.action": np.zeros(32, np.int32), "players.id": np.zeros(32, np.int32)}
+  for t in range(45):
+    obs, rew, term, trunc, info = env.step(act)
+    o._send(dummy_action(ids)); w = o._recv()
+    assert np.array_equal(obs["raw"], w[8]) and np.array_equal(term, w[3] & ~w[7]) and np.array_equal(trunc, w[7])
+    assert np.array_equal(info["elapsed_step"], w[2]) and np.array_equal(info["players"]["done"], w[10])
+    assert rew.tobytes() == w[4].tobytes()
+  # step a subset by env_id
+  sub = np.array([9, 3, 20], np.int32)
+  a2 = {k: v[:3] for k, v in act.items()}
+  obs, rew, term, trunc, info = env.step(a2, env_id=sub)
+  o._send(dummy_action(sub)); w = o._recv()
+  assert info["env_id"].tolist() == [9, 3, 20] and np.array_equal(obs["raw"], w[8])
+  assert "Dummy" in repr(env) and len(env) == 32
+
+
+def test_make_async_and_lazy_dyn():
+  import envpool_amd
+  from envpool_amd.python.lazy import LazyDyn
+  env = envpool_amd.make("Dummy-v0", "raw", num_envs=2048, batch_size=512, seed=1)
+  assert env.is_async
+  env.async_reset()
+  seen = []
+  for _ in range(4):
+    obs, info = env.recv(reset=True)
+    assert obs["raw"].shape == (512, 10)
+    assert isinstance(obs["dyn"], LazyDyn) and obs["dyn"][5].shape == (int(info["env_id"][5]) + 1, 10)
+    seen.append(info["env_id"])
+  assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(2048))
+
+
+def test_device_views_and_torch_interop():
+  import torch
+  from envpool_amd.dummy.dummy_envpool import _DummyEnvPool, _DummyEnvSpec
+  from envpool_amd.interop import as_torch
+  from oracle.dummy_oracle import DummyOracle
+  n = 512
+  spec = _DummyEnvSpec((n, 0, 0, 1, -1, "envpool2", 7, False, 2**31 - 1, 10, 6))
+  pool, o = _DummyEnvPool(spec), DummyOracle(num_envs=n, seed=7)
+  ids = np.arange(n, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  t_ids = torch.from_numpy(ids).to(dev)
+  t_la = torch.full((n, 6), 2.0, dtype=torch.float64, device=dev)
+  torch.cuda.synchronize()
+  pool._reset(ids); o._reset(ids)
+  for t in range(10):
+    descs, rows, prows = pool._recv_device()
+    w = o._recv()
+    assert rows == n and prows == n
+    got = [None if d is None else as_torch(d, dev).cpu().numpy() for d in descs]
+    assert_batches_equal(got, w, f"t={t}")
+    pool._send_device([t_ids.data_ptr(), t_ids.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr()], [n] * 5)
+    o._send(dummy_action(ids))
