@@ -16,7 +16,7 @@ HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HIP_DEPS := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inl) $(wildcard include/*.h)
 PYMODS := envpool_amd/dummy/dummy_envpool$(EXT) $(if $(wildcard $(CSRC)/py_ygopro.cpp),envpool_amd/ygopro/ygopro_envpool$(EXT))
 
-all: lib pymod oracle
+all: lib pymod oracle synth
 
 lib: $(LIB)
 
@@ -36,8 +36,13 @@ envpool_amd/ygopro/ygopro_envpool$(EXT): $(CSRC)/py_ygopro.cpp $(CSRC)/py_common
 oracle:
 	$(MAKE) -C oracle
 
+synth: tools/libygosynth.so
+
+tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpool_amd.h
+	gcc -O2 -fPIC -shared -std=c11 -Wall -o $@ $<
+
 clean:
-	rm -f $(LIB) $(PYMODS)
+	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib pymod oracle clean
+.PHONY: all lib pymod oracle synth clean

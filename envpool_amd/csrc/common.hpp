@@ -1,0 +1,73 @@
+// common.hpp — small host-side helpers shared by the translation units of libenvpool_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/envpool_amd.h"
+
+namespace epc {
+
+inline thread_local std::string g_last_error;
+
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return ::epc::fail(EP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                                \
+  } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+// A pool of pinned host blocks that outlives its owner if numpy still holds a batch (the
+// reference hands out buffers that are never reused, py_envpool.h:42-46).
+struct HostBlocks {
+  std::mutex mu;
+  std::vector<void*> free_list;
+  size_t bytes = 0;
+  bool alive = true;
+};
+struct HostBlockOwner {
+  std::shared_ptr<HostBlocks> home;
+  void* ptr;
+};
+
+inline int take_block(const std::shared_ptr<HostBlocks>& hb, void** out) {
+  void* blk = nullptr;
+  {
+    std::lock_guard<std::mutex> bl(hb->mu);
+    if (!hb->free_list.empty()) {
+      blk = hb->free_list.back();
+      hb->free_list.pop_back();
+    }
+  }
+  if (!blk) HIP_TRY(hipHostMalloc(&blk, hb->bytes, hipHostMallocDefault));
+  *out = blk;
+  return EP_OK;
+}
+
+inline void retire_blocks(const std::shared_ptr<HostBlocks>& hb) {
+  std::lock_guard<std::mutex> lk(hb->mu);
+  hb->alive = false;
+  for (void* b : hb->free_list) (void)hipHostFree(b);
+  hb->free_list.clear();
+}
+
+}  // namespace epc

@@ -25,48 +25,17 @@
 #include <string>
 #include <vector>
 
-#include "../../include/envpool_amd.h"
 #include "dummy_kernels.hpp"
 #include "dummy_mp_kernels.hpp"
 #include "dummy_rollout_wave.hpp"
 
+#include "common.hpp"
+
 namespace {
-
-thread_local std::string g_last_error;
-
-int fail(int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                     \
-  do {                                                                                    \
-    hipError_t _e = (expr);                                                               \
-    if (_e != hipSuccess)                                                                 \
-      return fail(EP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
-                  __LINE__);                                                              \
-  } while (0)
-
-constexpr size_t kAlign = 256;
-inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
-
-// A pool of pinned host blocks that outlives the ep_pool if numpy still holds a batch
-// (the reference hands out buffers that are never reused, py_envpool.h:42-46).
-struct HostBlocks {
-  std::mutex mu;
-  std::vector<void*> free_list;
-  size_t bytes = 0;
-  bool alive = true;
-};
-struct HostBlockOwner {
-  std::shared_ptr<HostBlocks> home;
-  void* ptr;
-};
+using epc::align_up;
+using epc::fail;
+using epc::HostBlockOwner;
+using epc::HostBlocks;
 
 struct SlotHost {
   uint64_t alloc_count = 0;  // StateBuffer::alloc_count_
@@ -368,7 +337,7 @@ int validate_ids_host(ep_pool* p, const int32_t* ids, int n) {
 
 extern "C" {
 
-const char* ep_last_error(void) { return g_last_error.c_str(); }
+const char* ep_last_error(void) { return epc::g_last_error.c_str(); }
 const char* ep_version(void) { return "envpool_amd 0.1 (gfx950)"; }
 
 int32_t ep_device_count(void) {
@@ -516,12 +485,7 @@ int ep_pool_destroy(ep_pool* p) {
   if (p->h_err) (void)hipHostFree(p->h_err);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   (void)hipFree(p->d_stage);
-  {
-    std::lock_guard<std::mutex> lk(p->blocks->mu);
-    p->blocks->alive = false;
-    for (void* b : p->blocks->free_list) (void)hipHostFree(b);
-    p->blocks->free_list.clear();
-  }
+  epc::retire_blocks(p->blocks);
   (void)hipStreamDestroy(p->stream);
   (void)hipStreamDestroy(p->copy_stream);
   delete p;
@@ -735,14 +699,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out) {
   char* base = nullptr;
   if (mem == EP_MEM_HOST) {
     void* blk = nullptr;
-    {
-      std::lock_guard<std::mutex> bl(p->blocks->mu);
-      if (!p->blocks->free_list.empty()) {
-        blk = p->blocks->free_list.back();
-        p->blocks->free_list.pop_back();
-      }
-    }
-    if (!blk) HIP_TRY(hipHostMalloc(&blk, p->slot_stride, hipHostMallocDefault));
+    if ((rc = epc::take_block(p->blocks, &blk))) return rc;
     char* src = p->d_ring + (size_t)slot * p->slot_stride;
     if ((size_t)nrows * 2 >= (size_t)p->B) {
       HIP_TRY(hipMemcpyAsync(blk, src, p->slot_stride, hipMemcpyDeviceToHost, p->stream));

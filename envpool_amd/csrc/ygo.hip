@@ -1,0 +1,831 @@
+// ygo.hip — host side of the YGOPro observation-encode tail: the encoder object (pinned
+// staging ring, side-stream H2D copies overlapped with the encode kernel), the static card
+// table upload, and the host adapter from the reference's own data forms to the POD record.
+// C ABI: include/envpool_amd_ygo.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "ygo_kernels.hpp"
+
+using epc::align_up;
+using epc::fail;
+
+namespace {
+
+struct Layout {  // record layout for one config
+  int nf, off_hist, off_cards, off_opts;
+  int64_t stride;
+};
+
+Layout make_layout(const ep_ygo_config& c) {
+  Layout l;
+  l.nf = 9 + 2 * c.max_multi_select;
+  l.off_hist = 64;
+  l.off_cards = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
+  l.off_opts = l.off_cards + 2 * c.max_cards * (int)sizeof(ygo_card);
+  l.off_opts = (l.off_opts + 15) & ~15;
+  l.stride = (int64_t)align_up((size_t)l.off_opts + (size_t)c.max_options * sizeof(ygo_option));
+  return l;
+}
+
+int check_config(const ep_ygo_config* c) {
+  if (!c) return fail(EP_ERR_INVALID, "null config");
+  if (c->max_cards < 1 || c->max_cards > 127) return fail(EP_ERR_INVALID, "max_cards must be in [1,127] (row indices travel in one byte, ygopro.h:1869)");
+  if (c->max_options < 1 || c->max_options > 64) return fail(EP_ERR_INVALID, "max_options must be in [1,64]");
+  if (c->n_history_actions < 1 || c->n_history_actions > 255) return fail(EP_ERR_INVALID, "n_history_actions must be in [1,255]");
+  if (c->max_multi_select < 1 || c->max_multi_select > EP_YGO_MAX_SPECS)
+    return fail(EP_ERR_INVALID, "max_multi_select must be in [1,%d]", EP_YGO_MAX_SPECS);
+  return EP_OK;
+}
+
+struct Slot {
+  char* h_rec = nullptr;   // pinned
+  char* d_rec = nullptr;
+  char* d_out = nullptr;   // all output keys of one batch
+  hipEvent_t copied = nullptr, done = nullptr;
+  int n = 0;
+  bool busy = false;
+};
+
+constexpr int kNumKeys = 17;
+
+}  // namespace
+
+struct ep_ygo_encoder {
+  ep_ygo_config cfg{};
+  Layout lay{};
+  int device = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  ygk::HashEntry* d_table = nullptr;
+  uint32_t table_mask = 0;
+  std::vector<Slot> slots;
+  uint32_t* h_err = nullptr;  // [ring] host-mapped
+  uint32_t* d_err = nullptr;
+  size_t key_off[kNumKeys]{};
+  size_t key_row[kNumKeys]{};
+  int key_dtype[kNumKeys]{};
+  size_t out_bytes = 0;
+  uint64_t submit_idx = 0, collect_idx = 0;
+  int lds_bytes = 0;
+  std::mutex mu;
+  std::shared_ptr<epc::HostBlocks> blocks;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+  double timed_total_us = 0;
+  int64_t timed_launches = 0;
+};
+
+namespace {
+
+void out_ptrs(ep_ygo_encoder* e, char* base, ygk::Outs* o) {
+  o->env_id = (int32_t*)(base + e->key_off[0]);
+  o->penv = (int32_t*)(base + e->key_off[1]);
+  o->elapsed = (int32_t*)(base + e->key_off[2]);
+  o->done = (uint8_t*)(base + e->key_off[3]);
+  o->reward = (float*)(base + e->key_off[4]);
+  o->discount = (float*)(base + e->key_off[5]);
+  o->step_type = (int32_t*)(base + e->key_off[6]);
+  o->trunc = (uint8_t*)(base + e->key_off[7]);
+  o->cards = (uint8_t*)(base + e->key_off[8]);
+  o->global = (uint8_t*)(base + e->key_off[9]);
+  o->actions = (uint8_t*)(base + e->key_off[10]);
+  o->h_actions = (uint8_t*)(base + e->key_off[11]);
+  o->num_options = (int32_t*)(base + e->key_off[12]);
+  o->to_play = (int32_t*)(base + e->key_off[13]);
+  o->is_selfplay = (int32_t*)(base + e->key_off[14]);
+  o->win_reason = (int32_t*)(base + e->key_off[15]);
+  o->h_card_ids = (uint16_t*)(base + e->key_off[16]);
+}
+
+int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
+  ygk::Args a;
+  a.records = (const uint8_t*)d_records;
+  a.stride = e->lay.stride;
+  a.n = n;
+  a.table = e->d_table;
+  a.table_mask = e->table_mask;
+  a.max_cards = e->cfg.max_cards;
+  a.max_options = e->cfg.max_options;
+  a.n_hist = e->cfg.n_history_actions;
+  a.mms = e->cfg.max_multi_select;
+  a.nf = e->lay.nf;
+  a.max_episode_steps = e->cfg.max_episode_steps;
+  a.off_hist = e->lay.off_hist;
+  a.off_cards = e->lay.off_cards;
+  a.off_opts = e->lay.off_opts;
+  out_ptrs(e, e->slots[slot].d_out, &a.out);
+  a.err = e->d_err + slot;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (e->timing) {
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, e->stream));
+  }
+  const int groups = (n + ygk::kGroup - 1) / ygk::kGroup;
+  hipLaunchKernelGGL(ygk::ygo_encode, dim3(groups), dim3(ygk::kThreads), e->lds_bytes, e->stream, a);
+  HIP_TRY(hipGetLastError());
+  if (e->timing) {
+    HIP_TRY(hipEventRecord(t1, e->stream));
+    e->timed.emplace_back(t0, t1);
+  }
+  return EP_OK;
+}
+
+int describe(ep_ygo_encoder* e, int slot, int32_t mem_out, ep_batch* out) {
+  Slot& s = e->slots[slot];
+  const int n = s.n;
+  memset(out, 0, sizeof(*out));
+  out->num_keys = kNumKeys;
+  out->mem = mem_out;
+  out->num_rows = n;
+  out->num_player_rows = n;
+  out->seq = e->collect_idx;
+  char* base = s.d_out;
+  if (mem_out == EP_MEM_HOST) {
+    void* blk = nullptr;
+    int rc = epc::take_block(e->blocks, &blk);
+    if (rc) return rc;
+    if (n * 2 >= e->cfg.max_batch) {
+      HIP_TRY(hipMemcpyAsync(blk, s.d_out, e->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    } else {
+      for (int k = 0; k < kNumKeys; ++k)
+        if (n) HIP_TRY(hipMemcpyAsync((char*)blk + e->key_off[k], s.d_out + e->key_off[k], (size_t)n * e->key_row[k], hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    out->owner = new epc::HostBlockOwner{e->blocks, blk};
+    base = (char*)blk;
+  }
+  const ep_ygo_config& c = e->cfg;
+  for (int k = 0; k < kNumKeys; ++k) {
+    ep_array& a = out->arrays[k];
+    a.data = base + e->key_off[k];
+    a.dtype = e->key_dtype[k];
+    a.ndim = 1;
+    a.shape[0] = n;
+  }
+  auto set3 = [&](int k, int d1, int d2) { out->arrays[k].ndim = 3; out->arrays[k].shape[1] = d1; out->arrays[k].shape[2] = d2; };
+  set3(8, 2 * c.max_cards, EP_YGO_CARD_FEATS);
+  out->arrays[9].ndim = 2; out->arrays[9].shape[1] = 8;
+  set3(10, c.max_options, e->lay.nf);
+  set3(11, c.n_history_actions, e->lay.nf);
+  set3(16, c.max_options, c.max_multi_select);
+  return EP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ep_ygo_record_stride(const ep_ygo_config* cfg) {
+  if (check_config(cfg)) return -1;
+  return make_layout(*cfg).stride;
+}
+
+int32_t ep_ygo_action_feats(const ep_ygo_config* cfg) { return cfg ? 9 + 2 * cfg->max_multi_select : 0; }
+
+int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
+  if (!out) return fail(EP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (cfg->max_batch < 1) return fail(EP_ERR_INVALID, "max_batch must be >= 1");
+  int ndev = ep_device_count();
+  if (ndev <= 0) return fail(EP_ERR_NO_DEVICE, "no HIP device visible: envpool_amd has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(EP_ERR_INVALID, "device_id %d out of range", cfg->device_id);
+  std::unique_ptr<ep_ygo_encoder> e(new ep_ygo_encoder());
+  e->cfg = *cfg;
+  if (e->cfg.ring_depth <= 0) e->cfg.ring_depth = 4;
+  e->lay = make_layout(*cfg);
+  e->device = cfg->device_id;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  const ygk::Carve cv = ygk::carve(cfg->max_cards, cfg->max_options, cfg->n_history_actions, cfg->max_multi_select);
+  e->lds_bytes = cv.total;
+  if (e->lds_bytes > 160 * 1024) return fail(EP_ERR_TOO_LARGE, "config needs %d bytes of LDS per workgroup (max 163840)", e->lds_bytes);
+  if (e->lds_bytes > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)ygk::ygo_encode, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+  // output block layout
+  const size_t B = (size_t)cfg->max_batch;
+  const int nf = e->lay.nf;
+  const size_t rowb[kNumKeys] = {4, 4, 4, 1, 4, 4, 4, 1, (size_t)2 * cfg->max_cards * EP_YGO_CARD_FEATS, 8,
+                                 (size_t)cfg->max_options * nf, (size_t)cfg->n_history_actions * nf, 4, 4, 4, 4,
+                                 (size_t)cfg->max_options * cfg->max_multi_select * 2};
+  const int dt[kNumKeys] = {EP_I32, EP_I32, EP_I32, EP_BOOL, EP_F32, EP_F32, EP_I32, EP_BOOL, EP_U8, EP_U8,
+                            EP_U8, EP_U8, EP_I32, EP_I32, EP_I32, EP_I32, EP_U16};
+  size_t off = 0;
+  for (int k = 0; k < kNumKeys; ++k) {
+    e->key_off[k] = off;
+    e->key_row[k] = rowb[k];
+    e->key_dtype[k] = dt[k];
+    off += align_up(B * rowb[k]);
+  }
+  e->out_bytes = off;
+  e->slots.resize(e->cfg.ring_depth);
+  for (auto& s : e->slots) {
+    HIP_TRY(hipHostMalloc((void**)&s.h_rec, (size_t)e->lay.stride * B, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&s.d_rec, (size_t)e->lay.stride * B));
+    HIP_TRY(hipMalloc((void**)&s.d_out, e->out_bytes));
+    HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  HIP_TRY(hipHostMalloc((void**)&e->h_err, 4 * e->slots.size(), hipHostMallocMapped));
+  memset(e->h_err, 0, 4 * e->slots.size());
+  HIP_TRY(hipHostGetDevicePointer((void**)&e->d_err, e->h_err, 0));
+  e->blocks = std::make_shared<epc::HostBlocks>();
+  e->blocks->bytes = e->out_bytes;
+  *out = e.release();
+  return EP_OK;
+}
+
+int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
+  if (!e) return EP_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->copy_stream);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& s : e->slots) {
+    if (s.h_rec) (void)hipHostFree(s.h_rec);
+    (void)hipFree(s.d_rec);
+    (void)hipFree(s.d_out);
+    if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (auto& ab : e->timed) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
+  if (e->h_err) (void)hipHostFree(e->h_err);
+  (void)hipFree(e->d_table);
+  epc::retire_blocks(e->blocks);
+  (void)hipStreamDestroy(e->stream);
+  (void)hipStreamDestroy(e->copy_stream);
+  delete e;
+  return EP_OK;
+}
+
+int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t n) {
+  if (!e || (!cards && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad card table");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  uint32_t cap = 64;
+  while (cap < (uint32_t)n * 2u) cap <<= 1;
+  std::vector<ygk::HashEntry> tab(cap);
+  memset(tab.data(), 0, sizeof(ygk::HashEntry) * cap);
+  for (int i = 0; i < n; ++i) {
+    const ygo_card_data& c = cards[i];
+    ygk::HashEntry h;
+    memset(&h, 0, sizeof(h));
+    h.code = c.code;
+    h.type = c.type;
+    h.attack = c.attack;
+    h.defense = c.defense;
+    h.card_id = c.card_id;
+    h.level = (uint8_t)c.level;
+    // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7
+    h.attr_id = 0xff;
+    if (c.attribute == 0) h.attr_id = 0;
+    else if ((c.attribute & (c.attribute - 1)) == 0 && c.attribute <= 0x40) h.attr_id = (uint8_t)(__builtin_ctz(c.attribute) + 1);
+    // race2id (:575-605): {0, bit0..bit25} -> 0..26
+    h.race_id = 0xff;
+    if (c.race == 0) h.race_id = 0;
+    else if ((c.race & (c.race - 1)) == 0 && c.race <= (1u << 25)) h.race_id = (uint8_t)(__builtin_ctz(c.race) + 1);
+    h.valid = 1;
+    uint32_t slot = (ygk::hash_code(c.code) >> 7) & (cap - 1);
+    while (tab[slot].valid && tab[slot].code != c.code) slot = (slot + 1) & (cap - 1);
+    tab[slot] = h;  // a repeated code keeps the last entry, like map[code] = ...
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(e->d_table);
+  e->d_table = nullptr;
+  HIP_TRY(hipMalloc((void**)&e->d_table, sizeof(ygk::HashEntry) * cap));
+  HIP_TRY(hipMemcpy(e->d_table, tab.data(), sizeof(ygk::HashEntry) * cap, hipMemcpyHostToDevice));
+  e->table_mask = cap - 1;
+  return EP_OK;
+}
+
+int ep_ygo_acquire_slot(ep_ygo_encoder* e, void** pinned_records) {
+  if (!e || !pinned_records) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->submit_idx - e->collect_idx >= e->slots.size())
+    return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
+  *pinned_records = e->slots[e->submit_idx % e->slots.size()].h_rec;
+  return EP_OK;
+}
+
+int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
+  if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
+  if (e->submit_idx - e->collect_idx >= e->slots.size())
+    return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
+  HIP_TRY(hipSetDevice(e->device));
+  const int si = (int)(e->submit_idx % e->slots.size());
+  Slot& s = e->slots[si];
+  s.n = n;
+  if (n > 0) {
+    // side-stream copy; the compute stream only waits for THIS batch's copy, so the copy of
+    // batch k+1 runs under the kernel of batch k
+    HIP_TRY(hipMemcpyAsync(s.d_rec, s.h_rec, (size_t)n * e->lay.stride, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+    int rc = launch(e, s.d_rec, n, si);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(s.done, e->stream));
+  s.busy = true;
+  e->submit_idx++;
+  return EP_OK;
+}
+
+int ep_ygo_submit(ep_ygo_encoder* e, const void* host_records, int32_t n) {
+  if (!e || (!host_records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
+  void* dst = nullptr;
+  int rc = ep_ygo_acquire_slot(e, &dst);
+  if (rc) return rc;
+  memcpy(dst, host_records, (size_t)n * e->lay.stride);
+  return ep_ygo_commit_slot(e, n);
+}
+
+int ep_ygo_collect(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
+  if (!e || !out) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->collect_idx == e->submit_idx) return fail(EP_ERR_WOULD_BLOCK, "nothing submitted");
+  HIP_TRY(hipSetDevice(e->device));
+  const int si = (int)(e->collect_idx % e->slots.size());
+  Slot& s = e->slots[si];
+  HIP_TRY(hipEventSynchronize(s.done));
+  int rc = describe(e, si, mem_out, out);
+  if (rc) return rc;
+  s.busy = false;
+  e->collect_idx++;
+  if (e->h_err[si]) {
+    e->h_err[si] = 0;
+    return fail(EP_ERR_ACTION_CHECK,
+                "a record hit a condition on which the reference throws (unknown card code / attribute / race / "
+                "position / phase, a spec that is not on the field, or more rows than max_cards)");
+  }
+  return EP_OK;
+}
+
+int ep_ygo_featurize(ep_ygo_encoder* e, const void* records, int32_t n, int32_t mem_in, int32_t mem_out, ep_batch* out) {
+  if (!e || !out || (!records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
+  if (mem_in == EP_MEM_HOST) {
+    int rc = ep_ygo_submit(e, records, n);
+    if (rc) return rc;
+    return ep_ygo_collect(e, mem_out, out);
+  }
+  // device-resident records: no staging, the kernel reads the caller's buffer
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
+    if (e->submit_idx - e->collect_idx >= e->slots.size()) return fail(EP_ERR_RING_FULL, "ring full");
+    HIP_TRY(hipSetDevice(e->device));
+    const int si = (int)(e->submit_idx % e->slots.size());
+    Slot& s = e->slots[si];
+    s.n = n;
+    if (n > 0) {
+      int rc = launch(e, (const char*)records, n, si);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(s.done, e->stream));
+    s.busy = true;
+    e->submit_idx++;
+  }
+  return ep_ygo_collect(e, mem_out, out);
+}
+
+int ep_ygo_sync(ep_ygo_encoder* e) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->copy_stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return EP_OK;
+}
+
+void* ep_ygo_stream(ep_ygo_encoder* e) { return e ? (void*)e->stream : nullptr; }
+
+int ep_ygo_set_timing(ep_ygo_encoder* e, int32_t enabled) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  e->timing = enabled != 0;
+  return EP_OK;
+}
+
+int ep_ygo_kernel_time_us(ep_ygo_encoder* e, double* total_us, int64_t* launches, int32_t reset) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  for (auto& ab : e->timed) {
+    HIP_TRY(hipEventSynchronize(ab.second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ab.first, ab.second));
+    e->timed_total_us += (double)ms * 1e3;
+    e->timed_launches++;
+    (void)hipEventDestroy(ab.first);
+    (void)hipEventDestroy(ab.second);
+  }
+  e->timed.clear();
+  if (total_us) *total_us = e->timed_total_us;
+  if (launches) *launches = e->timed_launches;
+  if (reset) { e->timed_total_us = 0; e->timed_launches = 0; }
+  return EP_OK;
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// Host adapter: reference data forms -> POD record. No GPU involved.
+// =========================================================================================
+namespace {
+
+constexpr uint32_t kQueryEquipCard = 0x4000;  // ygopro-core common.h QUERY_EQUIP_CARD
+constexpr uint32_t kLenEmpty = 4;             // ygopro-core LEN_EMPTY
+constexpr uint8_t kLocationOverlay = 0x80;
+
+struct Reader {
+  const uint8_t* b;
+  int len, p = 0;
+  bool ok = true;
+  uint32_t u32() {
+    if (p + 4 > len) { ok = false; p = len; return 0; }
+    uint32_t v;
+    memcpy(&v, b + p, 4);
+    p += 4;
+    return v;
+  }
+  uint8_t u8() {
+    if (p + 1 > len) { ok = false; p = len; return 0; }
+    return b[p++];
+  }
+};
+
+// get_cards_in_location (ygopro.h:2060-2137) without the static-table copy: that lookup happens
+// on the device.
+int parse_location(const uint8_t* buf, int len, std::vector<ygo_card>* out) {
+  Reader r{buf, len};
+  while (r.p < r.len) {
+    uint32_t f = r.u32();
+    if (f == kLenEmpty) continue;
+    f = r.u32();
+    ygo_card c;
+    memset(&c, 0, sizeof(c));
+    c.code = r.u32();
+    c.controller = r.u8();
+    c.location = r.u8();
+    c.sequence = r.u8();
+    c.position = r.u8();
+    c.level = (uint8_t)(r.u32() & 0xff);
+    c.rank = (uint8_t)(r.u32() & 0xff);
+    c.attack = (int32_t)r.u32();
+    c.defense = (int32_t)r.u32();
+    if (f & kQueryEquipCard) r.u32();
+    const uint32_t n_xyz = r.u32();
+    for (uint32_t i = 0; i < n_xyz && r.ok; ++i) {
+      ygo_card m;
+      memset(&m, 0, sizeof(m));
+      m.code = r.u32();
+      m.controller = c.controller;
+      m.location = c.location | kLocationOverlay;
+      m.sequence = c.sequence;
+      m.position = (uint8_t)i;
+      m.is_material = 1;
+      out->push_back(m);
+    }
+    const uint32_t n_counters = r.u32();
+    for (uint32_t i = 0; i < n_counters && r.ok; ++i) r.u32();
+    r.u32();  // lscale
+    r.u32();  // rscale
+    c.link = (uint8_t)(r.u32() & 0xff);
+    const uint32_t link_marker = r.u32();
+    if (link_marker > 0) c.defense = (int32_t)link_marker;
+    if (!r.ok) return fail(EP_ERR_INVALID, "truncated query_field_card buffer");
+    out->push_back(c);
+  }
+  return EP_OK;
+}
+
+// spec string ("oh3", "m2", "x1", "12", "m3a") -> key; mirrors spec_to_ls (:367-400) but keeps
+// the presence of the overlay suffix, which the string comparison of spec2index distinguishes.
+bool spec_key(const std::string& s, uint32_t* key) {
+  size_t i = 0;
+  uint32_t opp = 0;
+  if (i < s.size() && s[i] == 'o') { opp = 1; ++i; }
+  if (i >= s.size()) return false;
+  uint32_t loc;
+  switch (s[i]) {
+    case 'h': loc = 0x02; ++i; break;
+    case 'm': loc = 0x04; ++i; break;
+    case 's': loc = 0x08; ++i; break;
+    case 'g': loc = 0x10; ++i; break;
+    case 'r': loc = 0x20; ++i; break;
+    case 'x': loc = 0x40; ++i; break;
+    default:
+      if (!isdigit((unsigned char)s[i])) return false;
+      loc = 0x01;
+  }
+  size_t j = i;
+  uint32_t v = 0;
+  while (j < s.size() && isdigit((unsigned char)s[j])) { v = v * 10 + (uint32_t)(s[j] - '0'); ++j; }
+  if (j == i || v == 0 || v > 256) return false;
+  uint32_t suf = 0;
+  if (j < s.size()) {
+    if (j + 1 != s.size() || s[j] < 'a' || s[j] > 'z') return false;
+    suf = (uint32_t)(s[j] - 'a') + 1;
+  }
+  *key = opp | (loc << 8) | ((v - 1) << 16) | (suf << 24);
+  return true;
+}
+
+int list_id(const char* list, char c) {
+  const char* p = c ? strchr(list, c) : nullptr;
+  return p ? (int)(p - list) + 1 : -1;
+}
+
+int place_id(const std::string& s) {  // cmd_place2id (:680-686)
+  size_t i = 0;
+  int base = 0;
+  if (!s.empty() && s[0] == 'o') { base = 15; i = 1; }
+  if (i + 2 != s.size()) return -1;
+  const int d = s[i + 1] - '0';
+  if (s[i] == 'm' && d >= 1 && d <= 7) return base + d;
+  if (s[i] == 's' && d >= 1 && d <= 8) return base + 7 + d;
+  return -1;
+}
+
+int msg_id(int msg) {  // msg2id (:660-669)
+  static const int msgs[14] = {11, 16, 15, 20, 19, 12, 13, 10, 26, 14, 18, 23, 24, 141};
+  for (int i = 0; i < 14; ++i)
+    if (msgs[i] == msg) return i + 1;
+  return -1;
+}
+
+int pos_id_host(int p) {
+  static const int keys[9] = {0x0, 0x1, 0x2, 0x3, 0x4, 0x5, 0x8, 0xa, 0xc};
+  for (int i = 0; i < 9; ++i)
+    if (keys[i] == p) return i;
+  return -1;
+}
+
+enum { F_MSG = 0, F_ACT, F_YESNO, F_PHASE, F_CANCEL, F_POSITION, F_OPTION, F_PLACE, F_ATTRIB };
+
+// The grammar of _set_obs_action (:1674-1765). `specs` receives the referenced spec strings.
+int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vector<std::string>* specs) {
+  memset(feats, 0, 9);
+  const int mid = msg_id(msg);
+  if (mid < 0) return fail(EP_ERR_INVALID, "Unsupported message %d", msg);
+  feats[F_MSG] = (uint8_t)mid;
+  if (option.empty()) return fail(EP_ERR_INVALID, "empty option string");
+  auto need = [&](int id, const char* what) -> int {
+    return id < 0 ? fail(EP_ERR_INVALID, "option '%s': unknown %s", option.c_str(), what) : EP_OK;
+  };
+  auto strip_effect = [](std::string* spec) -> uint8_t {
+    if (!spec->empty() && isalpha((unsigned char)spec->back())) {
+      uint8_t off = (uint8_t)(spec->back() - 'a');
+      spec->pop_back();
+      return off;
+    }
+    return 0;
+  };
+  int rc;
+  switch (msg) {
+    case 11: {  // MSG_SELECT_IDLECMD
+      if (option == "b" || option == "e") {
+        feats[F_PHASE] = (uint8_t)list_id("bme", option[0]);
+      } else {
+        const char act = option[0];
+        std::string spec = option.size() >= 2 ? option.substr(2) : std::string();
+        uint8_t off = 0;
+        if (act == 'v') off = strip_effect(&spec);
+        if ((rc = need(list_id("trcsmav", act), "act"))) return rc;
+        feats[F_ACT] = (uint8_t)(list_id("trcsmav", act) + off);
+        specs->push_back(spec);
+      }
+      break;
+    }
+    case 16: {  // MSG_SELECT_CHAIN
+      if (option[0] == 'c') {
+        feats[F_CANCEL] = 1;
+      } else {
+        std::string spec = option;
+        const uint8_t off = strip_effect(&spec);
+        feats[F_ACT] = (uint8_t)(7 + off);  // 'v'
+        specs->push_back(spec);
+      }
+      break;
+    }
+    case 15: case 20: case 23: {  // CARD / TRIBUTE / SUM: space separated specs
+      size_t start = 0;
+      while (start < option.size()) {
+        const size_t idx = option.find(' ', start);
+        if (idx == std::string::npos) { specs->push_back(option.substr(start)); break; }
+        specs->push_back(option.substr(start, idx - start));
+        start = idx + 1;
+      }
+      break;
+    }
+    case 26: {  // MSG_SELECT_UNSELECT_CARD
+      if (option[0] == 'f') feats[F_CANCEL] = 2;
+      else specs->push_back(option);
+      break;
+    }
+    case 19: {  // MSG_SELECT_POSITION
+      const int sh = option[0] - '1';
+      const int pid = (sh >= 0 && sh < 8) ? pos_id_host(1 << sh) : -1;
+      if ((rc = need(pid, "position"))) return rc;
+      feats[F_POSITION] = (uint8_t)pid;
+      break;
+    }
+    case 12: {  // MSG_SELECT_EFFECTYN
+      specs->push_back(option.size() >= 2 ? option.substr(2) : std::string());
+      if ((rc = need(list_id("yn", option[0]), "yes/no"))) return rc;
+      feats[F_YESNO] = (uint8_t)list_id("yn", option[0]);
+      break;
+    }
+    case 13: {  // MSG_SELECT_YESNO
+      if ((rc = need(list_id("yn", option[0]), "yes/no"))) return rc;
+      feats[F_YESNO] = (uint8_t)list_id("yn", option[0]);
+      break;
+    }
+    case 10: {  // MSG_SELECT_BATTLECMD
+      if (option == "m" || option == "e") {
+        feats[F_PHASE] = (uint8_t)list_id("bme", option[0]);
+      } else {
+        if ((rc = need(list_id("trcsmav", option[0]), "act"))) return rc;
+        feats[F_ACT] = (uint8_t)list_id("trcsmav", option[0]);
+        specs->push_back(option.size() >= 2 ? option.substr(2) : std::string());
+      }
+      break;
+    }
+    case 14:  // MSG_SELECT_OPTION
+      feats[F_OPTION] = (uint8_t)(option[0] - '0');
+      break;
+    case 18: case 24: {  // PLACE / DISFIELD
+      if ((rc = need(place_id(option), "place"))) return rc;
+      feats[F_PLACE] = (uint8_t)place_id(option);
+      break;
+    }
+    case 141: {  // MSG_ANNOUNCE_ATTRIB: attribute2id.at(1 << (c - '1'))
+      const int sh = option[0] - '1';
+      if (sh < 0 || sh > 6) return fail(EP_ERR_INVALID, "option '%s': unknown attribute", option.c_str());
+      feats[F_ATTRIB] = (uint8_t)(sh + 1);
+      break;
+    }
+    default:
+      return fail(EP_ERR_INVALID, "Unsupported message %d", msg);
+  }
+  return EP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out) {
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (!in || !record_out) return fail(EP_ERR_INVALID, "null argument");
+  const Layout lay = make_layout(*cfg);
+  uint8_t* rec = (uint8_t*)record_out;
+  memset(rec, 0, (size_t)lay.stride);
+  ygo_header* h = (ygo_header*)rec;
+  if (in->to_play < 0 || in->to_play > 1) return fail(EP_ERR_INVALID, "to_play must be 0 or 1");
+  h->to_play = (uint8_t)in->to_play;
+  h->turn_player = (uint8_t)in->turn_player;
+  h->msg = (uint8_t)in->msg;
+  h->num_options = (uint8_t)std::min(in->n_options, 255);
+  h->is_selfplay = in->is_selfplay ? 1 : 0;
+  h->revealed_any = in->n_revealed != 0 ? 1 : 0;
+  h->ha_p = (uint8_t)in->ha_p[in->to_play];
+  h->done = in->done ? 1 : 0;
+  h->env_id = in->env_id;
+  h->elapsed_step = in->elapsed_step;
+  h->lp[0] = in->lp[0];
+  h->lp[1] = in->lp[1];
+  h->current_phase = in->current_phase;
+  h->win_reason = in->win_reason;
+  h->reward = in->reward;
+  if (in->ha_p[in->to_play] < 0 || in->ha_p[in->to_play] >= cfg->n_history_actions)
+    return fail(EP_ERR_INVALID, "ha_p outside the ring");
+  // revealed_: only entries that name an opponent hand card can matter (:1541-1545)
+  for (int i = 0; i < in->n_revealed; ++i) {
+    uint32_t key;
+    if (in->revealed[i] && spec_key(in->revealed[i], &key) && (key & 0xff) == 1 && ((key >> 8) & 0xff) == 0x02 &&
+        (key >> 24) == 0) {
+      const uint32_t seq = (key >> 16) & 0xff;
+      if (seq < 64) h->revealed_hand_mask |= 1ull << seq;
+    }
+  }
+  if (in->history[in->to_play])
+    memcpy(rec + lay.off_hist, in->history[in->to_play], (size_t)cfg->n_history_actions * lay.nf);
+  if (in->n_options == 0) return EP_OK;  // WriteState's early-out reads nothing else (:1837-1841)
+
+  std::vector<ygo_card> cards;
+  for (int pi = 0; pi < 2; ++pi) {
+    const int player = (in->to_play + pi) % 2;
+    for (int li = 0; li < 7; ++li) {
+      bool hidden = (li == 0 || li == 1 || li == 6);
+      if (li == 1 && in->n_revealed != 0) hidden = false;
+      if (pi == 1 && hidden) {
+        const int cnt = in->field_count[player][li];
+        if (cnt < 0 || cnt > 255) return fail(EP_ERR_INVALID, "field count %d out of range", cnt);
+        h->loc_count[pi][li] = (uint8_t)cnt;
+      } else {
+        const size_t before = cards.size();
+        if (in->field_buf[player][li] && in->field_len[player][li] > 0)
+          if ((rc = parse_location(in->field_buf[player][li], in->field_len[player][li], &cards))) return rc;
+        const size_t cnt = cards.size() - before;
+        if (cnt > 255) return fail(EP_ERR_INVALID, "location holds %zu cards", cnt);
+        h->loc_count[pi][li] = (uint8_t)cnt;
+      }
+    }
+  }
+  if ((int)cards.size() > 2 * cfg->max_cards)
+    return fail(EP_ERR_INVALID, "%zu listed cards exceed 2*max_cards = %d (the reference overruns obs:cards_ here)",
+                cards.size(), 2 * cfg->max_cards);
+  memcpy(rec + lay.off_cards, cards.data(), cards.size() * sizeof(ygo_card));
+  const int n_opt = std::min(in->n_options, cfg->max_options);
+  ygo_option* opts = (ygo_option*)(rec + lay.off_opts);
+  for (int i = 0; i < n_opt; ++i) {
+    std::vector<std::string> specs;
+    if (!in->options[i]) return fail(EP_ERR_INVALID, "null option string");
+    if ((rc = parse_option(in->msg, in->options[i], opts[i].feats, &specs))) return rc;
+    if ((int)specs.size() > cfg->max_multi_select)
+      return fail(EP_ERR_INVALID, "option '%s' references %zu specs, more than max_multi_select", in->options[i], specs.size());
+    opts[i].n_specs = (uint8_t)specs.size();
+    for (size_t j = 0; j < specs.size(); ++j) {
+      // a malformed spec can never be a key of spec2index: give it a key no row carries, so the
+      // device reports the same "throw" the reference's .at() would
+      if (!spec_key(specs[j], &opts[i].spec_key[j])) opts[i].spec_key[j] = 0xfffffffeu;
+    }
+  }
+  return EP_OK;
+}
+
+int ep_ygo_emit_records(const ep_ygo_config* cfg, const ygo_raw_state* in, int32_t n, void* records_out,
+                        int32_t* status) {
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  const int64_t stride = make_layout(*cfg).stride;
+  int first = EP_OK;
+  for (int i = 0; i < n; ++i) {
+    rc = ep_ygo_emit_record(cfg, in + i, (char*)records_out + (int64_t)i * stride);
+    if (status) status[i] = rc;
+    if (rc && !first) first = rc;
+  }
+  return first;
+}
+
+int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, int32_t msg, const char* option,
+                        const uint16_t* card_ids, int32_t n_card_ids) {
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  if (!ring || !ha_p || !option) return fail(EP_ERR_INVALID, "null argument");
+  const int nf = 9 + 2 * cfg->max_multi_select;
+  uint8_t feats[9];
+  std::vector<std::string> specs;
+  if ((rc = parse_option(msg, option, feats, &specs))) return rc;
+  // with an empty spec2index the spec columns carry card ids (:1625): CARD/TRIBUTE/SUM write one
+  // per card id (:1711-1714), every other spec-bearing option writes card_ids[0]
+  int n_write = 0;
+  if (msg == 15 || msg == 20 || msg == 23) n_write = n_card_ids;
+  else if (!specs.empty()) n_write = 1;
+  if (n_write > n_card_ids) return fail(EP_ERR_INVALID, "option '%s' needs a card id (the reference reads card_ids[0] out of bounds)", option);
+  if (n_write > cfg->max_multi_select) return fail(EP_ERR_INVALID, "more card ids than max_multi_select");
+  int p = *ha_p - 1;
+  if (p < 0) p = cfg->n_history_actions - 1;
+  *ha_p = p;
+  uint8_t* row = ring + (size_t)p * nf;
+  for (int j = 0; j < n_write; ++j) {
+    row[2 * j] = (uint8_t)(card_ids[j] >> 8);
+    row[2 * j + 1] = (uint8_t)(card_ids[j] & 0xff);
+  }
+  // only the columns the message's branch assigns are touched; the rest keep their old bytes
+  const int off = 2 * cfg->max_multi_select;
+  row[off + F_MSG] = feats[F_MSG];
+  auto put = [&](int f) { row[off + f] = feats[f]; };
+  switch (msg) {
+    case 11: if (option[0] && (strcmp(option, "b") == 0 || strcmp(option, "e") == 0)) put(F_PHASE); else put(F_ACT); break;
+    case 16: if (option[0] == 'c') put(F_CANCEL); else put(F_ACT); break;
+    case 26: if (option[0] == 'f') put(F_CANCEL); break;
+    case 19: put(F_POSITION); break;
+    case 12: put(F_YESNO); break;
+    case 13: put(F_YESNO); break;
+    case 10: if (strcmp(option, "m") == 0 || strcmp(option, "e") == 0) put(F_PHASE); else put(F_ACT); break;
+    case 14: put(F_OPTION); break;
+    case 18: case 24: put(F_PLACE); break;
+    case 141: put(F_ATTRIB); break;
+    default: break;
+  }
+  return EP_OK;
+}
+
+}  // extern "C"

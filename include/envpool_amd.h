@@ -54,7 +54,8 @@ enum {
   EP_F64 = 2,
   EP_BOOL = 3, /* 1 byte, 0/1 */
   EP_U8 = 4,
-  EP_CONTAINER_I32 = 5 /* ragged Container<int> (spec.h:96-109): no device array, see obs:dyn */
+  EP_CONTAINER_I32 = 5, /* ragged Container<int> (spec.h:96-109): no device array, see obs:dyn */
+  EP_U16 = 6
 };
 
 #define EP_MAX_KEYS 20

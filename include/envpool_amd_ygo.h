@@ -1,0 +1,197 @@
+/*
+ * envpool_amd_ygo.h — C ABI of the YGOPro observation-encode tail on MI355X.
+ *
+ * What moves to the GPU (BASELINE.json north_star): everything YGOProEnv::WriteState
+ * (envpool2/ygopro/ygopro.h:1828-1893) does after the duel engine has stopped at a
+ * decision — obs:cards_ (:1508-1603), obs:global_ (:1605-1620), obs:actions_
+ * (:1674-1765, :1821-1826), the obs:h_actions_ ring copy-out (:1881-1892), the scalar
+ * info keys and the common StateBuffer fields (envpool2/core/env.h:196-222).
+ * The Lua/SQLite duel engine (ygopro-core) stays on host threads and is NOT part of
+ * this library: its output reaches the GPU as one fixed-stride POD record per env
+ * (layout below), written by the host into pinned memory.
+ *
+ * The reference has no struct at this seam (WriteState reads engine state through
+ * query_field_card / query_field_count and the options_ strings), so the record is a new
+ * contract; `ep_ygo_emit_record` is the host-side adapter that builds it from exactly the
+ * reference-form data (raw query buffers, option strings, revealed_ strings), and the
+ * parity tests prove oracle(reference form) == GPU(emit(reference form)).
+ */
+#ifndef ENVPOOL_AMD_YGO_H_
+#define ENVPOOL_AMD_YGO_H_
+
+#include <stdint.h>
+
+#include "envpool_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- config (ygopro.h:1179-1186 defaults) --------------------------------- */
+typedef struct {
+  int32_t max_cards;         /* per player; obs:cards_ has 2*max_cards rows (default 75) */
+  int32_t max_options;       /* default 16 */
+  int32_t n_history_actions; /* default 16 */
+  int32_t max_multi_select;  /* default 5; n_action_feats = 9 + 2*max_multi_select (:1189) */
+  int32_t max_episode_steps; /* common config (env_spec.h:30), for `trunc` */
+  int32_t device_id;
+  int32_t ring_depth;        /* in-flight batches of the submit/collect pipeline (0 => 4) */
+  int32_t max_batch;         /* largest n of one featurize/submit call */
+} ep_ygo_config;
+
+#define EP_YGO_CARD_FEATS 39 /* ygopro.h:1191 */
+#define EP_YGO_MAX_SPECS 8   /* >= max_multi_select */
+
+/* ---- the per-env record ---------------------------------------------------
+ * record := ygo_header (64 B)
+ *           | history ring of the to_play player, n_history_actions*n_action_feats bytes,
+ *             raw ring order (ygopro.h:1304-1314), padded to 16 B
+ *           | ygo_card[2*max_cards]        (only the first sum(loc_count of listed
+ *                                           locations) entries are meaningful)
+ *           | ygo_option[max_options]
+ * padded to a multiple of 256 B: ep_ygo_record_stride(). */
+typedef struct {
+  uint8_t to_play;      /* to_play_ (:1281) */
+  uint8_t turn_player;  /* tp_ (:1275) */
+  uint8_t msg;          /* msg_ (:1279), raw MSG_SELECT_* / MSG_ANNOUNCE_ATTRIB value */
+  uint8_t num_options;  /* options_.size() BEFORE the max_options truncation (:1849-1851), capped at 255 */
+  uint8_t is_selfplay;  /* play_mode_ == kSelfPlay (:1834) */
+  uint8_t revealed_any; /* revealed_.size() != 0 (:1522-1525) */
+  uint8_t ha_p;         /* ring pointer of to_play_ (:1883) */
+  uint8_t done;         /* Env::IsDone() (env.h:199) */
+  int32_t env_id;       /* env.h:208 */
+  int32_t elapsed_step; /* env.h:209 */
+  int32_t lp[2];        /* lp_ by ABSOLUTE player (:1272) */
+  int32_t current_phase;/* current_phase_ (:1276), raw PHASE_* bit */
+  int32_t win_reason;   /* value passed to WriteState (:1493 / :1422) */
+  float reward;
+  uint64_t revealed_hand_mask; /* bit k set <=> "oh<k+1>" is in revealed_ (:1541-1545) */
+  /* per pi (0 = to_play, 1 = opponent) and location in the order DECK, HAND, MZONE, SZONE,
+   * GRAVE, REMOVED, EXTRA (:1514-1519): number of rows that location contributes — the
+   * query_field_count for a hidden opponent location (:1527), else the number of ygo_card
+   * entries (overlay materials included, :2106-2115). */
+  uint8_t loc_count[2][7];
+  uint8_t pad[2];
+} ygo_header; /* 64 bytes */
+
+/* One card of a listed location, in get_cards_in_location order (:2060-2137): overlay
+ * materials come before their host monster and carry location|0x80, position = index. */
+typedef struct {
+  uint32_t code;      /* CardCode */
+  uint8_t controller; /* ABSOLUTE player id */
+  uint8_t location;   /* LOCATION_* | LOCATION_OVERLAY(0x80) */
+  uint8_t sequence;
+  uint8_t position;   /* POS_* ; overlay index for materials */
+  uint8_t level;      /* low byte of the queried level (0 if not > 0)  (:2090-2093) */
+  uint8_t rank;       /* low byte of the queried rank                   (:2094-2097) */
+  uint8_t link;       /* low byte of the queried link rating            (:2126-2130) */
+  uint8_t is_material;/* 1 for overlay materials: every dynamic field below is absent (:2109-2114) */
+  int32_t attack;     /* queried attack (:2098) */
+  int32_t defense;    /* queried defense, or link_marker when that is > 0 (:2099, :2131-2133) */
+} ygo_card; /* 20 bytes */
+
+/* One option after the host has applied the per-message grammar of _set_obs_action
+ * (:1674-1765): the nine spec-independent feature bytes (columns 2*mms .. 2*mms+8) and the
+ * referenced specs as keys to be resolved against the card rows on the device. */
+typedef struct {
+  uint8_t feats[9];  /* msg, act(+offset), yes/no, phase, cancel/finish, position, option, place, attrib */
+  uint8_t n_specs;   /* 0..max_multi_select */
+  uint8_t pad[2];
+  /* key = opponent | (location&0x7f)<<8 | sequence<<16 | (has_suffix ? pos+1 : 0)<<24,
+   * "opponent" relative to to_play (a leading 'o', :358-365); suffix = overlay letter (:352-354) */
+  uint32_t spec_key[EP_YGO_MAX_SPECS];
+} ygo_option; /* 44 bytes */
+
+/* ---- static card table (replaces init_module's cards_/card_ids_, ygopro.h:1030-1064) -- */
+typedef struct {
+  uint32_t code;
+  uint32_t type;      /* TYPE_* bits */
+  uint32_t level;     /* already masked & 0xff by db_query_card (:849) */
+  uint32_t attribute; /* ATTRIBUTE_* bit */
+  uint32_t race;      /* RACE_* bit */
+  int32_t attack;     /* static atk: what an overlay material shows (c_get_card copy, :2109) */
+  int32_t defense;    /* static def; 0 for LINK monsters (:855-858) */
+  uint16_t card_id;   /* code-list index (:1034-1041) */
+  uint16_t pad;
+} ygo_card_data; /* 32 bytes */
+
+typedef struct ep_ygo_encoder ep_ygo_encoder;
+
+int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out);
+int ep_ygo_encoder_destroy(ep_ygo_encoder* enc);
+
+/* Uploads the static table as an open-addressing hash keyed by code (device resident). */
+int ep_ygo_set_card_table(ep_ygo_encoder* enc, const ygo_card_data* cards, int32_t n);
+
+int64_t ep_ygo_record_stride(const ep_ygo_config* cfg);
+int32_t ep_ygo_action_feats(const ep_ygo_config* cfg);
+
+/* Replaces: WriteState (ygopro.h:1828-1893) + Env::Allocate (env.h:196-222) for a batch of
+ * `n` records. `records` is host (pageable or pinned) or device memory per `mem_in`; the
+ * result is described in `out` as in ep_pool_recv, keys in the reference's `_state_keys`
+ * order (8 common keys, then obs:cards_, obs:global_, obs:actions_, obs:h_actions_,
+ * info:num_options, info:to_play, info:is_selfplay, info:win_reason) followed by one
+ * additive key: aux:h_card_ids uint16 [n, max_options, max_multi_select] (the
+ * back-derivation of :1863-1879, so the host ring update needs no GPU read-back of obs).
+ * Blocking. Returns EP_ERR_ACTION_CHECK when a record tripped a condition on which the
+ * reference throws (unknown card code / attribute / race / position / phase / message,
+ * spec not on the field, more rows than max_cards); the batch is still returned. */
+int ep_ygo_featurize(ep_ygo_encoder* enc, const void* records, int32_t n, int32_t mem_in,
+                     int32_t mem_out, ep_batch* out);
+
+/* Pipelined form: submit copies the host records into the next pinned staging slot,
+ * enqueues the H2D copy on a side stream and the kernel on the compute stream, and returns;
+ * collect hands out the oldest submitted batch. Up to ring_depth batches in flight, so the
+ * copy of batch k+1 overlaps the kernel of batch k (north_star: "pinned hipMemcpyAsync
+ * overlap of host duel results on a side stream"). */
+int ep_ygo_submit(ep_ygo_encoder* enc, const void* host_records, int32_t n);
+int ep_ygo_collect(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);
+/* Direct access to the next pinned staging slot, so host duel threads can emit records in
+ * place (no memcpy): acquire -> fill n records -> commit. */
+int ep_ygo_acquire_slot(ep_ygo_encoder* enc, void** pinned_records);
+int ep_ygo_commit_slot(ep_ygo_encoder* enc, int32_t n);
+int ep_ygo_sync(ep_ygo_encoder* enc);
+void* ep_ygo_stream(ep_ygo_encoder* enc);
+int ep_ygo_set_timing(ep_ygo_encoder* enc, int32_t enabled);
+int ep_ygo_kernel_time_us(ep_ygo_encoder* enc, double* total_us, int64_t* launches, int32_t reset);
+
+/* ---- host-side adapter from the reference's own data forms ----------------
+ * Everything WriteState reads from YGOProEnv, as plain pointers. */
+typedef struct {
+  int32_t to_play, turn_player, msg, current_phase, is_selfplay, win_reason;
+  int32_t lp[2];
+  float reward;
+  int32_t env_id, elapsed_step, done;
+  int32_t n_options;
+  const char* const* options;  /* options_ (:1280) */
+  int32_t n_revealed;
+  const char* const* revealed; /* revealed_ (:1316) */
+  /* by ABSOLUTE player and location order DECK..EXTRA: query_field_count (:1527) and the raw
+   * query_field_card buffer with the flags of :2061-2064 (may be NULL when count-only) */
+  int32_t field_count[2][7];
+  const uint8_t* field_buf[2][7];
+  int32_t field_len[2][7];
+  const uint8_t* history[2]; /* history_actions_0_/1_ (:1307,:1312), n_history*n_feats bytes each */
+  int32_t ha_p[2];           /* ha_p_0_/ha_p_1_ */
+} ygo_raw_state;
+
+/* Parses the raw query buffers (get_cards_in_location, :2060-2137) and the option strings
+ * (grammar of _set_obs_action, :1674-1765) into one record. Host only, no GPU. Returns
+ * EP_ERR_INVALID on input the reference would throw on while parsing. */
+int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
+
+/* `n` consecutive ep_ygo_emit_record calls; record i goes to records_out + i*stride.
+ * status[i] (may be NULL) receives each call's code; returns the first non-OK code. */
+int ep_ygo_emit_records(const ep_ygo_config* cfg, const ygo_raw_state* in, int32_t n, void* records_out,
+                        int32_t* status);
+
+/* Host ring update of YGOProEnv::update_history_actions (:1439-1450) with the card ids of
+ * the chosen option (aux:h_card_ids row): moves *ha_p and encodes `option` into the ring.
+ * Untouched columns keep their old bytes (the reference never clears a reused row). */
+int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, int32_t msg,
+                        const char* option, const uint16_t* card_ids, int32_t n_card_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVPOOL_AMD_YGO_H_ */

@@ -1,0 +1,169 @@
+"""CPU: the YGOPro oracle (oracle/ygo_oracle.c) against the hand-derived known answers, the
+host record emitter (product, host-only) against what the oracle implies, the history-ring
+update, and oracle <-> emitter consistency on synthetic states."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from envpool_amd import capi_ygo
+from oracle import ygo_oracle
+from tests import ygo_build
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ygo_known_answers.json")))
+K = capi_ygo.YGO_STATE_KEYS
+
+
+def _cfg(**kw):
+  return capi_ygo.default_config(**kw)
+
+
+def _run_oracle(case):
+  cfg = _cfg()
+  table = ygo_build.make_table(GOLD["table"])
+  arr, keep = ygo_build.batch_of([case["state"]])
+  outs, status = ygo_oracle.write_batch(cfg, table, arr, 1)
+  return dict(zip(K, outs)), status
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_known_answers(case):
+  o, status = _run_oracle(case)
+  assert status[0] == 0
+  e = case["expect"]
+  for key, name in (("num_options", "info:num_options"), ("to_play", "info:to_play"), ("is_selfplay", "info:is_selfplay"),
+                    ("win_reason", "info:win_reason"), ("step_type", "step_type"), ("env_id", "info:env_id"),
+                    ("elapsed_step", "elapsed_step"), ("done", "done"), ("trunc", "trunc")):
+    if key in e:
+      assert int(o[name][0]) == e[key], key
+  for key, name in (("reward", "reward"), ("discount", "discount")):
+    if key in e:
+      assert float(o[name][0]) == e[key], key
+  assert o["obs:global_"][0].tolist() == e["global"]
+  cards = o["obs:cards_"][0]
+  for r, row in e.get("cards_rows", {}).items():
+    assert cards[int(r)].tolist() == row, f"cards row {r}"
+  assert np.nonzero(cards.any(axis=1))[0].tolist() == e["nonzero_card_rows"]
+  for r, row in e.get("actions_rows", {}).items():
+    assert o["obs:actions_"][0][int(r)].tolist() == row, f"actions row {r}"
+  for r, row in e.get("h_card_ids", {}).items():
+    assert o["aux:h_card_ids"][0][int(r)].tolist() == row, f"h_card_ids row {r}"
+
+
+def test_float_transform_and_lp():
+  table = ygo_build.make_table(GOLD["table"])
+  for x, want in GOLD["float_transform"].items():
+    st = {"to_play": 0, "options": ["y"], "msg": 13, "lp": [int(x), 0]}
+    arr, keep = ygo_build.batch_of([st])
+    outs, status = ygo_oracle.write_batch(_cfg(), table, arr, 1)
+    assert status[0] == 0 and outs[9][0][:2].tolist() == want, x
+
+
+def test_history_rotation():
+  table = ygo_build.make_table(GOLD["table"])
+  ring = np.repeat(np.arange(1, 17, dtype=np.uint8)[:, None], 19, axis=1)
+  for hp, want in GOLD["history_rotation"]["ha_p"].items():
+    st = {"to_play": 1, "options": ["y"], "msg": 13, "history": {"p1": ring}, "ha_p": [3, int(hp)]}
+    arr, keep = ygo_build.batch_of([st])
+    outs, _ = ygo_oracle.write_batch(_cfg(), table, arr, 1)
+    assert outs[11][0][:, 0].tolist() == want and (outs[11][0] == outs[11][0][:, :1]).all()
+
+
+@pytest.mark.parametrize("st", [
+  {"options": ["s h1"], "msg": 11},                                     # spec not on the field
+  {"options": ["y"], "msg": 99},                                        # unsupported message
+  {"options": ["y"], "msg": 13, "phase": 3},                            # phase2id.at throws
+  {"options": ["y"], "msg": 13, "field": {"p0": {"hand": [{"code": 424242, "seq": 0}]}}},  # unknown code
+  {"options": ["y"], "msg": 13, "field": {"p0": {"mzone": [{"code": 89631139, "seq": 0, "pos": 6}]}}},  # bad position
+])
+def test_conditions_where_the_reference_throws(st):
+  table = ygo_build.make_table(GOLD["table"])
+  arr, keep = ygo_build.batch_of([st])
+  _, status = ygo_oracle.write_batch(_cfg(), table, arr, 1)
+  assert status[0] == 6
+
+
+def test_emitter_record_fields():
+  """ep_ygo_emit_record parses the same buffers/strings into the POD record."""
+  case = GOLD["cases"][2]
+  cfg = _cfg()
+  arr, keep = ygo_build.batch_of([case["state"]])
+  recs, status = capi_ygo.emit_records(cfg, arr, 1)
+  assert status[0] == 0
+  rec = recs[0]
+  assert recs.shape[1] == capi_ygo.lib().ep_ygo_record_stride(C.byref(cfg)) and recs.shape[1] % 256 == 0
+  assert rec[0] == 1 and rec[1] == 1 and rec[2] == 15 and rec[3] == 2 and rec[5] == 1  # to_play tp msg n_opt revealed_any
+  mask = int(np.frombuffer(rec[40:48].tobytes(), np.uint64)[0])
+  assert mask == 1  # only "oh1" matters; "g9" is not an opponent-hand spec
+  loc = rec[48:62].reshape(2, 7)
+  assert loc.tolist() == [[0, 0, 3, 0, 0, 0, 0], [2, 2, 0, 0, 0, 0, 0]]
+  off_cards = 64 + ((16 * 19 + 15) // 16) * 16
+  cards = np.frombuffer(rec[off_cards:off_cards + 5 * 20].tobytes(), dtype=np.dtype(
+    [("code", "<u4"), ("ctrl", "u1"), ("loc", "u1"), ("seq", "u1"), ("pos", "u1"), ("level", "u1"), ("rank", "u1"),
+     ("link", "u1"), ("mat", "u1"), ("atk", "<i4"), ("def", "<i4")]))
+  assert cards["code"].tolist() == [46986414, 55144522, 10000, 55144522, 89631139]
+  assert cards["loc"].tolist() == [0x84, 0x84, 0x04, 0x02, 0x02] and cards["mat"].tolist() == [1, 1, 0, 0, 0]
+  assert cards["pos"].tolist()[:2] == [0, 1] and cards["rank"][2] == 4 and cards["atk"][2] == -2
+  off_opts = (off_cards + 150 * 20 + 15) // 16 * 16
+  opt0 = rec[off_opts:off_opts + 44]
+  assert opt0[0] == 3 and opt0[9] == 2  # msg id, n_specs
+  keys = np.frombuffer(opt0[12:20].tobytes(), "<u4").tolist()
+  assert keys == [0 | (0x04 << 8) | (0 << 16) | (1 << 24), 1 | (0x02 << 8) | (0 << 16)]
+
+
+@pytest.mark.parametrize("msg,opt,feat_col,val", [
+  (11, "e", 3, 3), (11, "t x2", 1, 1), (11, "v g3c", 1, 9), (16, "c", 4, 1), (16, "os2b", 1, 8), (26, "f", 4, 2),
+  (19, "3", 5, 4), (19, "4", 5, 6), (12, "n oh1", 2, 2), (13, "y", 2, 1), (10, "a m1", 1, 6), (10, "m", 3, 2),
+  (14, "7", 6, 7), (18, "os8", 7, 30), (24, "m7", 7, 7), (141, "6", 8, 6),
+])
+def test_emitter_option_grammar(msg, opt, feat_col, val):
+  """The nine spec-independent feature bytes, message by message (:1674-1765 with the id tables
+  :660-686): e.g. 'v g3c' -> act v(7)+('c'-'a')=9; POSITION '4' -> 1<<3=8 -> position2id 6."""
+  cfg = _cfg()
+  arr, keep = ygo_build.batch_of([{"msg": msg, "options": [opt]}])
+  recs, status = capi_ygo.emit_records(cfg, arr, 1)
+  assert status[0] == 0
+  off_cards = 64 + 304
+  off_opts = (off_cards + 150 * 20 + 15) // 16 * 16
+  feats = recs[0][off_opts:off_opts + 9].tolist()
+  want = [0] * 9
+  want[0] = [11, 16, 15, 20, 19, 12, 13, 10, 26, 14, 18, 23, 24, 141].index(msg) + 1
+  want[feat_col] = val
+  assert feats == want
+
+
+def test_history_push_matches_oracle_and_keeps_stale_bytes():
+  cfg = _cfg()
+  L = capi_ygo.lib()
+  rng = np.random.default_rng(0)
+  ring_a = rng.integers(0, 30, size=(16, 19)).astype(np.uint8)
+  ring_b = ring_a.copy()
+  pa, pb = 2, 2
+  script = [(11, "s h1", [300]), (11, "b", []), (16, "m2b", [7]), (15, "m1 oh2 g3", [1, 2, 3]), (13, "n", []),
+            (12, "y s3", [9]), (10, "a m1", [1025]), (26, "f", []), (19, "2", []), (14, "3", []), (18, "om4", []),
+            (141, "5", []), (11, "v x1c", [65535])]
+  for msg, opt, ids in script * 2:  # wraps the 16-row ring: reused rows keep untouched columns (Q10)
+    rc, pa = ygo_oracle.history_push(cfg, ring_a, pa, msg, opt, ids)
+    assert rc == 0
+    p = C.c_int32(pb)
+    idarr = np.asarray(ids, np.uint16)
+    assert L.ep_ygo_history_push(C.byref(cfg), ring_b.ctypes.data, C.byref(p), msg, opt.encode(), idarr.ctypes.data, len(ids)) == 0
+    pb = p.value
+    assert pa == pb and np.array_equal(ring_a, ring_b), (msg, opt)
+
+
+def test_synthetic_states_are_well_formed():
+  """The generator feeds both sides of the GPU parity test: most states must encode cleanly, and
+  the emitter must accept exactly the states the oracle accepts."""
+  from tools import ygo_synth
+  cfg = _cfg()
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, 3000, seed=0)
+  outs, status = ygo_oracle.write_batch(cfg, table, sb.raw, sb.n)
+  recs, est = capi_ygo.emit_records(cfg, sb.raw, sb.n)
+  assert (status == 0).mean() > 0.95, np.unique(status, return_counts=True)
+  assert (est == 0).all()
+  nopt = outs[12]
+  assert nopt.min() >= 1 and nopt.max() == 16 and (outs[8].reshape(3000, -1).any(axis=1)).mean() > 0.95

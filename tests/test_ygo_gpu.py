@@ -1,0 +1,131 @@
+"""GPU parity of the YGOPro observation-encode kernel, through the C ABI: for reference-form
+states S, kernel(ep_ygo_emit_record(S)) == oracle(S), bit for bit on every key.
+(The oracle is pinned by hand-derived vectors only: parity unpinned by reference data.)"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from envpool_amd import capi, capi_ygo
+from tests import ygo_build
+
+pytestmark = pytest.mark.gpu
+K = capi_ygo.YGO_STATE_KEYS
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ygo_known_answers.json")))
+
+
+def _compare(got, want, rows, ctx=""):
+  for k, name in enumerate(K):
+    g, w = np.asarray(got[k])[rows], np.asarray(want[k])[rows]
+    assert g.dtype == w.dtype and g.shape == w.shape, f"{ctx} {name}: {g.dtype}{g.shape} vs {w.dtype}{w.shape}"
+    if g.tobytes() != w.tobytes():
+      bad = np.nonzero((g.reshape(len(rows), -1) != w.reshape(len(rows), -1)).any(axis=1))[0]
+      r = bad[0]
+      raise AssertionError(f"{ctx} {name}: {len(bad)} envs differ, first env {rows[r]}:\n got {g[r]}\nwant {w[r]}")
+
+
+def test_known_answers_on_gpu():
+  from oracle import ygo_oracle
+  cfg = capi_ygo.default_config(max_batch=64)
+  table = ygo_build.make_table(GOLD["table"])
+  arr, keep = ygo_build.batch_of([c["state"] for c in GOLD["cases"]])
+  n = len(GOLD["cases"])
+  want, status = ygo_oracle.write_batch(cfg, table, arr, n)
+  assert (status == 0).all()
+  recs, est = capi_ygo.emit_records(cfg, arr, n)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  got = enc.featurize(recs)
+  _compare(got, want, np.arange(n), "known answers")
+  e = GOLD["cases"][0]["expect"]
+  assert got[8][0][1].tolist() == e["cards_rows"]["1"] and got[10][0][2].tolist() == e["actions_rows"]["2"]
+
+
+@pytest.mark.parametrize("n,seed,kw", [
+  (1, 1, {}), (7, 2, {}), (8, 3, {}), (1000, 4, {}), (20000, 5, {}),
+  (513, 6, dict(max_cards=60, max_options=12, n_history_actions=8, max_multi_select=3)),
+  (300, 7, dict(max_cards=100, max_options=24, n_history_actions=20, max_multi_select=8)),
+])
+def test_synthetic_parity(n, seed, kw):
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  cfg = capi_ygo.default_config(max_batch=max(n, 8), **kw)
+  table = ygo_synth.make_table(1000, seed=seed)
+  sb = ygo_synth.SynthBatch(cfg, table, n, seed=seed)
+  want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
+  recs, est = capi_ygo.emit_records(cfg, sb.raw, n)
+  ok = np.nonzero((status == 0) & (est == 0))[0]
+  assert len(ok) > 0.9 * n
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  got = enc.featurize(recs, allow=(capi.EP_ERR_ACTION_CHECK,))
+  # the batch reports "the reference would throw" exactly when the oracle says so for some record
+  assert (enc.last_status == capi.EP_ERR_ACTION_CHECK) == bool(((status != 0) & (est == 0)).any())
+  _compare(got, want, ok, f"n={n} seed={seed}")
+
+
+def test_throw_conditions_are_reported():
+  from oracle import ygo_oracle
+  cfg = capi_ygo.default_config(max_batch=16)
+  table = ygo_build.make_table(GOLD["table"])
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  good = GOLD["cases"][0]["state"]
+  for st in ({"options": ["s h1"], "msg": 11}, {"options": ["y"], "msg": 13, "phase": 3},
+             {"options": ["y"], "msg": 13, "field": {"p0": {"hand": [{"code": 424242, "seq": 0}]}}},
+             {"options": ["y"], "msg": 13, "field": {"p0": {"mzone": [{"code": 89631139, "seq": 0, "pos": 6}]}}}):
+    arr, keep = ygo_build.batch_of([good, st, good])
+    _, status = ygo_oracle.write_batch(cfg, table, arr, 3)
+    assert status.tolist() == [0, 6, 0]
+    recs, est = capi_ygo.emit_records(cfg, arr, 3)
+    assert (est == 0).all()
+    enc.featurize(recs, allow=(capi.EP_ERR_ACTION_CHECK,))
+    assert enc.last_status == capi.EP_ERR_ACTION_CHECK
+  arr, keep = ygo_build.batch_of([good])
+  recs, _ = capi_ygo.emit_records(cfg, arr, 1)
+  enc.featurize(recs)
+  assert enc.last_status == 0  # the flag does not stick
+
+
+def test_submit_collect_pipeline_and_device_records():
+  """Several batches in flight (pinned staging + side-stream copy), results in FIFO order;
+  device-resident records give the same bytes."""
+  import torch
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  cfg = capi_ygo.default_config(max_batch=256, ring_depth=3)
+  table = ygo_synth.make_table(500, seed=9)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  L = capi_ygo.lib()
+  batches = []
+  for b in range(7):
+    n = [256, 100, 8, 255, 1, 64, 200][b]
+    sb = ygo_synth.SynthBatch(cfg, table, n, seed=100 + b)
+    want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
+    recs, est = capi_ygo.emit_records(cfg, sb.raw, n)
+    batches.append((recs, want, np.nonzero((status == 0) & (est == 0))[0]))
+  pending = []
+  for recs, want, ok in batches:
+    if len(pending) == 3:
+      with pytest.raises(capi.EpError) as e:
+        enc.submit(recs)
+      assert e.value.code == capi.EP_ERR_RING_FULL
+      w, o = pending.pop(0)
+      _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), w, o, "pipelined")
+    enc.submit(recs)
+    pending.append((want, ok))
+  while pending:
+    w, o = pending.pop(0)
+    _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), w, o, "drain")
+  with pytest.raises(capi.EpError) as e:
+    enc.collect()
+  assert e.value.code == capi.EP_ERR_WOULD_BLOCK
+  # device-resident records, device views out
+  recs, want, ok = batches[0]
+  t = torch.from_numpy(recs.copy()).to("cuda:0")
+  torch.cuda.synchronize()
+  bt = capi.Batch()
+  rc = L.ep_ygo_featurize(enc.handle, t.data_ptr(), recs.shape[0], capi.EP_MEM_DEVICE, capi.EP_MEM_HOST, C.byref(bt))
+  assert rc in (0, capi.EP_ERR_ACTION_CHECK)
+  got = capi.batch_to_numpy(bt)
+  L.ep_batch_release(C.byref(bt))
+  _compare(got, want, ok, "device records")

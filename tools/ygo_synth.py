@@ -1,0 +1,45 @@
+"""ctypes front-end of tools/ygo_synth.c: synthetic duel states in the reference's data forms."""
+import ctypes as C
+import os
+import subprocess
+
+from envpool_amd.capi_ygo import CardData, RawState, YgoConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+  global _LIB
+  if _LIB is None:
+    path = os.path.join(_HERE, "libygosynth.so")
+    if not os.path.exists(path):
+      subprocess.check_call(["make", "-s", "-C", os.path.dirname(_HERE), "synth"])
+    L = C.CDLL(path)
+    L.ys_make_table.argtypes = [C.c_int32, C.c_uint64, C.POINTER(CardData)]
+    L.ys_gen_batch.restype = C.c_void_p
+    L.ys_gen_batch.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.POINTER(YgoConfig), C.POINTER(CardData), C.c_int32,
+                               C.POINTER(RawState)]
+    L.ys_free_batch.argtypes = [C.c_void_p, C.c_int32]
+    _LIB = L
+  return _LIB
+
+
+def make_table(n=1000, seed=0):
+  t = (CardData * n)()
+  lib().ys_make_table(n, seed, t)
+  return t
+
+
+class SynthBatch:
+  """n synthetic states; `.raw` is a ctypes array of ygo_raw_state valid while this object lives."""
+
+  def __init__(self, cfg, table, n, seed=0, first=0):
+    self.n = n
+    self.raw = (RawState * max(n, 1))()
+    self._h = lib().ys_gen_batch(seed, first, n, C.byref(cfg), table, len(table), self.raw)
+
+  def __del__(self):
+    if getattr(self, "_h", None):
+      lib().ys_free_batch(self._h, self.n)
+      self._h = None
