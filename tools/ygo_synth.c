@@ -52,7 +52,7 @@ void ys_make_table(int32_t n, uint64_t seed, ygo_card_data* out) {
   }
 }
 
-#define YS_MAX_OPT 24
+#define YS_MAX_OPT 72
 typedef struct {
   ygo_raw_state raw;
   uint8_t* buf[2][7];
@@ -245,7 +245,7 @@ ys_state* ys_gen(uint64_t seed, int64_t index, const ep_ygo_config* cfg, const y
   int n_opt = rint_(&r, 2, 16);
   const int roll = rint_(&r, 0, 99);
   if (roll == 0) n_opt = 0;
-  else if (roll < 3) n_opt = rint_(&r, cfg->max_options + 1, YS_MAX_OPT);
+  else if (roll < 3 && cfg->max_options + 1 <= YS_MAX_OPT) n_opt = rint_(&r, cfg->max_options + 1, cfg->max_options + 8 < YS_MAX_OPT ? cfg->max_options + 8 : YS_MAX_OPT);
   else if (roll < 6) n_opt = 1;
   if (n_opt > YS_MAX_OPT) n_opt = YS_MAX_OPT;
   raw->n_options = n_opt;
