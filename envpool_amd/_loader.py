@@ -11,7 +11,9 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libenvpool_amd.so")
+# ENVPOOL_AMD_LIB points diagnostics at an alternative build of the same library (e.g. the
+# -DYGO_STAMPS one); the product default is the in-tree library.
+LIB_PATH = os.environ.get("ENVPOOL_AMD_LIB") or os.path.join(_HERE, "libenvpool_amd.so")
 _lib = None
 
 

@@ -67,10 +67,12 @@ struct ep_ygo_encoder {
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   ygk::HashEntry* d_table = nullptr;
+  ygk::HashAux* d_table_aux = nullptr;
   uint32_t table_mask = 0;
   std::vector<Slot> slots;
   uint32_t* h_err = nullptr;  // [ring] host-mapped
   uint32_t* d_err = nullptr;
+  unsigned long long* d_stamps = nullptr;  // diagnostic builds (-DYGO_STAMPS)
   size_t key_off[kNumKeys]{};
   size_t key_row[kNumKeys]{};
   int key_dtype[kNumKeys]{};
@@ -113,6 +115,7 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
   a.stride = e->lay.stride;
   a.n = n;
   a.table = e->d_table;
+  a.table_aux = e->d_table_aux;
   a.table_mask = e->table_mask;
   a.max_cards = e->cfg.max_cards;
   a.max_options = e->cfg.max_options;
@@ -125,6 +128,7 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
   a.off_opts = e->lay.off_opts;
   out_ptrs(e, e->slots[slot].d_out, &a.out);
   a.err = e->d_err + slot;
+  a.stamps = e->d_stamps;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (e->timing) {
     HIP_TRY(hipEventCreate(&t0));
@@ -244,6 +248,10 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   HIP_TRY(hipHostGetDevicePointer((void**)&e->d_err, e->h_err, 0));
   e->blocks = std::make_shared<epc::HostBlocks>();
   e->blocks->bytes = e->out_bytes;
+#ifdef YGO_STAMPS
+  HIP_TRY(hipMalloc((void**)&e->d_stamps, 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(e->d_stamps, 0, 16 * sizeof(unsigned long long)));
+#endif
   *out = e.release();
   return EP_OK;
 }
@@ -253,6 +261,16 @@ int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->copy_stream);
   (void)hipStreamSynchronize(e->stream);
+#ifdef YGO_STAMPS
+  {
+    unsigned long long st[16];
+    (void)hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost);
+    unsigned long long tot = 0;
+    for (int k = 0; k < 8; ++k) tot += st[k];
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "[ygo stamps] phase %d: %5.1f%%\n", k, 100.0 * (double)st[k] / (double)(tot ? tot : 1));
+    (void)hipFree(e->d_stamps);
+  }
+#endif
   for (auto& s : e->slots) {
     if (s.h_rec) (void)hipHostFree(s.h_rec);
     (void)hipFree(s.d_rec);
@@ -263,6 +281,7 @@ int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
   for (auto& ab : e->timed) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
   if (e->h_err) (void)hipHostFree(e->h_err);
   (void)hipFree(e->d_table);
+  (void)hipFree(e->d_table_aux);
   epc::retire_blocks(e->blocks);
   (void)hipStreamDestroy(e->stream);
   (void)hipStreamDestroy(e->copy_stream);
@@ -277,15 +296,15 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
   uint32_t cap = 64;
   while (cap < (uint32_t)n * 2u) cap <<= 1;
   std::vector<ygk::HashEntry> tab(cap);
+  std::vector<ygk::HashAux> aux(cap);
   memset(tab.data(), 0, sizeof(ygk::HashEntry) * cap);
+  memset(aux.data(), 0, sizeof(ygk::HashAux) * cap);
   for (int i = 0; i < n; ++i) {
     const ygo_card_data& c = cards[i];
     ygk::HashEntry h;
     memset(&h, 0, sizeof(h));
     h.code = c.code;
-    h.type = c.type;
-    h.attack = c.attack;
-    h.defense = c.defense;
+    h.type = c.type | ygk::kEntryValid;  // TYPE_* uses bits 0..26
     h.card_id = c.card_id;
     h.level = (uint8_t)c.level;
     // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7
@@ -296,16 +315,21 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
     h.race_id = 0xff;
     if (c.race == 0) h.race_id = 0;
     else if ((c.race & (c.race - 1)) == 0 && c.race <= (1u << 25)) h.race_id = (uint8_t)(__builtin_ctz(c.race) + 1);
-    h.valid = 1;
     uint32_t slot = (ygk::hash_code(c.code) >> 7) & (cap - 1);
-    while (tab[slot].valid && tab[slot].code != c.code) slot = (slot + 1) & (cap - 1);
+    while ((tab[slot].type & ygk::kEntryValid) && tab[slot].code != c.code) slot = (slot + 1) & (cap - 1);
     tab[slot] = h;  // a repeated code keeps the last entry, like map[code] = ...
+    aux[slot].attack = c.attack;
+    aux[slot].defense = c.defense;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->d_table);
+  (void)hipFree(e->d_table_aux);
   e->d_table = nullptr;
+  e->d_table_aux = nullptr;
   HIP_TRY(hipMalloc((void**)&e->d_table, sizeof(ygk::HashEntry) * cap));
+  HIP_TRY(hipMalloc((void**)&e->d_table_aux, sizeof(ygk::HashAux) * cap));
   HIP_TRY(hipMemcpy(e->d_table, tab.data(), sizeof(ygk::HashEntry) * cap, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_table_aux, aux.data(), sizeof(ygk::HashAux) * cap, hipMemcpyHostToDevice));
   e->table_mask = cap - 1;
   return EP_OK;
 }

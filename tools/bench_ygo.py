@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""YGOPro observation-encode throughput (GPU box). Prints one JSON object.
+
+Workloads: BASELINE config 3 shape (n=1024 records per call, host records through the pinned
+submit/collect pipeline) and a large device-resident batch for the kernel's roofline figure."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
+  import numpy as np
+  import torch
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  L = capi_ygo.lib()
+  cfg = capi_ygo.default_config(max_batch=n_big, ring_depth=2)
+  table = ygo_synth.make_table(1000, seed=0)
+  n_gen = 8192
+  sb = ygo_synth.SynthBatch(cfg, table, n_gen, seed=0)
+  t0 = time.perf_counter()
+  recs, est = capi_ygo.emit_records(cfg, sb.raw, n_gen)
+  emit_s = time.perf_counter() - t0
+  stride = recs.shape[1]
+  # algorithmic bytes per record: what the kernel must read (header + history + listed cards +
+  # options actually present) and write (every output key)
+  hdr = recs[:, :64]
+  loc = hdr[:, 48:62].reshape(-1, 2, 7).astype(np.int64)
+  revealed_any = hdr[:, 5].astype(bool)
+  listed = loc[:, 0, :].sum(1) + loc[:, 1, 2:6].sum(1) + np.where(revealed_any, loc[:, 1, 1], 0)
+  n_opt = np.minimum(hdr[:, 3].astype(np.int64), cfg.max_options)
+  nf = 9 + 2 * cfg.max_multi_select
+  read_b = 64 + cfg.n_history_actions * nf + listed * 20 + n_opt * 44
+  read_b = np.where(hdr[:, 3] == 0, 64, read_b)
+  write_b = 2 * cfg.max_cards * 39 + 8 + cfg.max_options * nf + cfg.n_history_actions * nf + 4 * 4 + (4 + 4 + 4 + 1 + 4 + 4 + 4 + 1) \
+      + cfg.max_options * cfg.max_multi_select * 2
+  alg_per_rec = float(read_b.mean() + write_b)
+
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  h = enc.handle
+  reps = n_big // n_gen
+  big = torch.from_numpy(np.tile(recs, (reps, 1))).to("cuda:0")
+  torch.cuda.synchronize()
+  b = capi.Batch()
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  for _ in range(3):
+    assert L.ep_ygo_featurize(h, big.data_ptr(), n_big, capi.EP_MEM_DEVICE, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  L.ep_ygo_set_timing(h, 1)
+  tot, cnt = C.c_double(), C.c_int64()
+  L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+  w0 = time.perf_counter()
+  for _ in range(iters):
+    assert L.ep_ygo_featurize(h, big.data_ptr(), n_big, capi.EP_MEM_DEVICE, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  w1 = time.perf_counter()
+  L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+  L.ep_ygo_set_timing(h, 0)
+  k_us = tot.value / max(1, cnt.value)
+  big_res = {"records_per_launch": n_big, "kernel_us": k_us, "encodes_per_s_kernel": n_big / (k_us * 1e-6),
+             "encodes_per_s_wall": n_big * iters / (w1 - w0), "alg_bytes_per_record": alg_per_rec,
+             "achieved_GBps": alg_per_rec * n_big / (k_us * 1e-6) / 1e9, "frac_of_8TBps": alg_per_rec * n_big / (k_us * 1e-6) / 8e12}
+  enc.close()
+
+  # config 3: 1024 host records per step through the pinned pipeline (copy of k+1 under kernel of k)
+  cfg3 = capi_ygo.default_config(max_batch=n_cfg3, ring_depth=4)
+  enc3 = capi_ygo.YgoEncoderC(cfg3, table, len(table))
+  h3 = enc3.handle
+  rec3 = np.ascontiguousarray(recs[:n_cfg3])
+  steps = 400
+  for _ in range(8):
+    L.ep_ygo_submit(h3, rec3.ctypes.data, n_cfg3)
+    L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b))
+  L.ep_ygo_set_timing(h3, 1)
+  L.ep_ygo_kernel_time_us(h3, C.byref(tot), C.byref(cnt), 1)
+  w0 = time.perf_counter()
+  inflight = 0
+  for s in range(steps):
+    assert L.ep_ygo_submit(h3, rec3.ctypes.data, n_cfg3) == 0
+    inflight += 1
+    if inflight == 3:
+      assert L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      inflight -= 1
+  while inflight:
+    assert L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    inflight -= 1
+  w1 = time.perf_counter()
+  L.ep_ygo_kernel_time_us(h3, C.byref(tot), C.byref(cnt), 1)
+  cfg3_res = {"records_per_step": n_cfg3, "steps": steps, "encodes_per_s_wall_pcie_inclusive": n_cfg3 * steps / (w1 - w0),
+              "us_per_step_wall": (w1 - w0) / steps * 1e6, "kernel_us": tot.value / max(1, cnt.value),
+              "record_stride_bytes": int(stride)}
+  enc3.close()
+
+  res = {"large_batch": big_res, "config3_host_pipeline": cfg3_res,
+         "host_emit_records_per_s_1core": n_gen / emit_s}
+  if cpu_seconds > 0:
+    from oracle import ygo_oracle
+    n_cpu = 2048
+    c0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - c0 < cpu_seconds:
+      ygo_oracle.write_batch(cfg, table, sb.raw, n_cpu)
+      done += n_cpu
+    res["cpu_oracle_encodes_per_s_1core"] = done / (time.perf_counter() - c0)
+  return res
+
+
+if __name__ == "__main__":
+  print(json.dumps(run(cpu_seconds=float(os.environ.get("EP_YGO_CPU_SECONDS", "3")))))
