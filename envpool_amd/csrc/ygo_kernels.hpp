@@ -5,15 +5,15 @@
 // Env::Allocate's common fields (envpool2/core/env.h:196-222), consuming the POD record of
 // include/envpool_amd_ygo.h instead of live engine queries.
 //
-// Mapping to the hardware: one 512-thread workgroup encodes EIGHT consecutive envs, one wave64
-// per env. Eight, because 8 * (2*max_cards*39) bytes is always a multiple of 16: the group's
-// obs:cards_ block is then a 16-byte-aligned contiguous span of the output tensor and leaves
-// the CU as full 16-byte-per-lane stores, although a single env's 5850-byte block is only
-// 2-byte aligned. Each wave builds its env's rows in an LDS image that starts out zeroed (the
-// reference's zero-filled StateBuffer, fused), resolves card codes through a device-resident
-// open-addressing hash (L2-resident), resolves the options' specs against the per-duel row
-// keys held in LDS (the reference's per-step spec2index hash map), and derives h_card_ids from
-// the image exactly as :1863-1879 reads them back from obs.
+// Mapping to the hardware: one wave64 encodes one env, and waves never talk to each other (no
+// workgroup barrier anywhere). A wave builds its env's rows in LDS images that start out zeroed
+// (the reference's zero-filled StateBuffer, fused). A single env's 5850-byte obs:cards_ block
+// is only 2-byte aligned in the output tensor, so every image sits in LDS at the SAME offset
+// modulo 16 as its destination in HBM: the bulk of the block then leaves the CU as aligned
+// 16-byte-per-lane stores, with at most 15 single bytes at either end. Card codes resolve
+// through a device-resident open-addressing hash (L2-resident), the options' specs through a
+// per-env direct-mapped table in LDS (the reference's per-step spec2index hash map), and
+// h_card_ids is derived from the image exactly as :1863-1879 reads it back from obs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,8 +22,11 @@
 
 namespace ygk {
 
-constexpr int kGroup = 8;     // envs per workgroup
-constexpr int kThreads = 512; // one wave64 per env
+#ifndef YGO_WAVES
+#define YGO_WAVES 4
+#endif
+constexpr int kGroup = YGO_WAVES;       // envs (= waves) per workgroup; any value works
+constexpr int kThreads = 64 * kGroup;   // one wave64 per env
 
 struct __align__(16) HashEntry {  // 16 bytes: one 16-byte load per probe
   uint32_t code;
@@ -62,11 +65,10 @@ struct Args {
 };
 
 __host__ __device__ inline int al16(int x) { return (x + 15) & ~15; }
-// per-workgroup LDS carve (byte offsets, every region 16-byte aligned). The five image regions
-// hold the eight envs' output blocks back to back (env w at w * per-env bytes, unpadded), so a
-// region leaves the CU as one contiguous span.
+// per-wave LDS arena (byte offsets inside it, all 16-byte aligned). Each image region has 16
+// spare bytes so that the image can start at its destination's address modulo 16.
 struct Carve {
-  int cards, actions, hact, global, hcids, spec, rowkey, total, spec_stride, rowkey_stride;
+  int cards, actions, hact, global, hcids, spec, rowkey, wave_stride, total, spec_stride, rowkey_stride;
 };
 // direct-mapped spec table of one env: [2 players][7 locations][max_cards sequences] plus
 // [2][8 monster zones][8 overlay letters], one byte each (1-based row index, 0 = absent)
@@ -75,16 +77,17 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   const int nf = 9 + 2 * mms, R = 2 * max_cards;
   Carve c;
   int o = 0;
-  c.cards = o;   o += al16(kGroup * R * 39);
-  c.actions = o; o += al16(kGroup * max_options * nf);
-  c.global = o;  o += al16(kGroup * 8);
-  c.hcids = o;   o += al16(kGroup * max_options * mms * 2);
-  c.hact = o;    o += al16(kGroup * n_hist * nf);
+  c.cards = o;   o += al16(R * 39) + 16;
+  c.actions = o; o += al16(max_options * nf) + 16;
+  c.hact = o;    o += al16(n_hist * nf) + 16;
+  c.hcids = o;   o += al16(max_options * mms * 2) + 16;
+  c.global = o;  o += 16;
   c.spec_stride = spec_table_bytes(max_cards);
-  c.spec = o;    o += kGroup * c.spec_stride;
-  c.rowkey_stride = al16(R * 4 + R);  // per env: key of listed card k (u32), then its row (u8)
-  c.rowkey = o;  o += kGroup * c.rowkey_stride;
-  c.total = o;
+  c.spec = o;    o += c.spec_stride;
+  c.rowkey_stride = al16(R * 4 + R);  // key of listed card k (u32), then its row (u8)
+  c.rowkey = o;  o += c.rowkey_stride;
+  c.wave_stride = o;
+  c.total = o * kGroup;
   return c;
 }
 // staging of one env's ygo_card / ygo_option arrays inside its own (not yet used) card image
@@ -130,11 +133,14 @@ __device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
   return 14 * max_cards + (int)((opp * 8 + seq) * 8 + (suf - 1));
 }
 
+#ifndef YGO_SKIP
+#define YGO_SKIP 0  // diagnostic builds: leave phases out to price them (results are then wrong)
+#endif
 #ifdef YGO_STAMPS
 #define YGO_STAMP(k)                                                                          \
   do {                                                                                        \
     unsigned long long _t = __builtin_amdgcn_s_memtime();                                     \
-    if (lane == 0) atomicAdd(&a.stamps[k], _t - _t_prev);                                     \
+    if (lane == 0 && (blockIdx.x & 63) == 0) atomicAdd(&a.stamps[k], _t - _t_prev);                                     \
     _t_prev = __builtin_amdgcn_s_memtime();                                                   \
   } while (0)
 #else
@@ -158,6 +164,23 @@ __device__ __forceinline__ void wave_zero(unsigned char* lds, int lo, int hi, in
   for (int q = (mlo >> 4) + lane; q < (mhi >> 4); q += 64) reinterpret_cast<uint4*>(lds)[q] = z;
 }
 
+// copy the LDS bytes [lo, lo+bytes) to g with one wave. When g and lo agree modulo 16 the bulk
+// goes as aligned 16-byte stores; otherwise (odd-aligned caller buffers) byte by byte.
+__device__ __forceinline__ void wave_flush(uint8_t* g, const unsigned char* lds, int lo, int bytes, int lane) {
+  if ((((uintptr_t)g ^ (uintptr_t)lo) & 15) == 0) {
+    const int head = min((16 - (lo & 15)) & 15, bytes);
+    if (lane < head) g[lane] = lds[lo + lane];
+    const int nvec = (bytes - head) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(lds + lo + head);
+    uint4* dst = reinterpret_cast<uint4*>(g + head);
+    for (int q = lane; q < nvec; q += 64) dst[q] = src[q];
+    const int done = head + (nvec << 4);
+    if (lane < bytes - done) g[done + lane] = lds[lo + done + lane];
+  } else {
+    for (int b = lane; b < bytes; b += 64) g[b] = lds[lo + b];
+  }
+}
+
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
@@ -177,15 +200,24 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
 
   if (wave < gvalid) {  // wave-uniform: one wave64 encodes one env, with no cross-wave traffic
     const uint8_t* rec = a.records + e * a.stride;
-    const int img_lo = cv.cards + wave * R * 39, img_hi = img_lo + R * 39;
+    const int arena = wave * cv.wave_stride;
+    // global destinations of this env's images, and LDS offsets congruent to them modulo 16
+    uint8_t* g_cards = a.out.cards + e * (int64_t)(R * 39);
+    uint8_t* g_actions = a.out.actions + e * (int64_t)(a.max_options * nf);
+    uint8_t* g_hact = a.out.h_actions + e * (int64_t)(a.n_hist * nf);
+    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
+    const int img_lo = arena + cv.cards + (int)((uintptr_t)g_cards & 15), img_hi = img_lo + R * 39;
+    const int act_lo = arena + cv.actions + (int)((uintptr_t)g_actions & 15);
+    const int hact_lo = arena + cv.hact + (int)((uintptr_t)g_hact & 15);
+    const int hcids_lo = arena + cv.hcids + (int)((uintptr_t)g_hcids & 14);  // keep uint16 alignment
     uint8_t* my_cards = lds + img_lo;
-    uint8_t* my_actions = lds + cv.actions + wave * a.max_options * nf;
-    uint8_t* my_hact = lds + cv.hact + wave * a.n_hist * nf;
-    uint8_t* my_global = lds + cv.global + wave * 8;
-    uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + cv.hcids) + wave * a.max_options * a.mms;
-    uint32_t* my_rowkey = reinterpret_cast<uint32_t*>(lds + cv.rowkey + wave * cv.rowkey_stride);
+    uint8_t* my_actions = lds + act_lo;
+    uint8_t* my_hact = lds + hact_lo;
+    uint8_t* my_global = lds + arena + cv.global;
+    uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + hcids_lo);
+    uint32_t* my_rowkey = reinterpret_cast<uint32_t*>(lds + arena + cv.rowkey);
     uint8_t* my_krow = reinterpret_cast<uint8_t*>(my_rowkey + R);
-    uint8_t* my_spec = lds + cv.spec + wave * cv.spec_stride;
+    uint8_t* my_spec = lds + arena + cv.spec;
 
     // ---- every global read of this env is issued up front as 16-byte-per-lane coalesced loads
     // (the record layout is fixed, so no address depends on the header): header, the ygo_card
@@ -213,10 +245,10 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
 
     // ---- while they fly: the env's small images start as zeros (the reference's fresh
     // zero-filled StateBuffer, array.h:77-81) ----
-    wave_zero(lds, cv.actions + wave * a.max_options * nf, cv.actions + (wave + 1) * a.max_options * nf, lane);
-    wave_zero(lds, cv.hact + wave * hist_bytes, cv.hact + (wave + 1) * hist_bytes, lane);
-    wave_zero(lds, cv.hcids + wave * a.max_options * a.mms * 2, cv.hcids + (wave + 1) * a.max_options * a.mms * 2, lane);
-    wave_zero(lds, cv.spec + wave * cv.spec_stride, cv.spec + (wave + 1) * cv.spec_stride, lane);
+    wave_zero(lds, act_lo, act_lo + a.max_options * nf, lane);
+    wave_zero(lds, hact_lo, hact_lo + hist_bytes, lane);
+    wave_zero(lds, hcids_lo, hcids_lo + a.max_options * a.mms * 2, lane);
+    wave_zero(lds, arena + cv.spec, arena + cv.spec + cv.spec_stride, lane);
     if (lane < 2) reinterpret_cast<uint32_t*>(my_global)[lane] = 0u;
 
     // ---- header: lanes 0..3 hold it; every field becomes a wave-uniform scalar ----
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
     }
     const int n_listed = min(n_cards, R);
     const bool overflow = rows_pi[0] > a.max_cards || rows_pi[1] > a.max_cards;
+    YGO_STAMP(0);
 
     if (no_options) {
       wave_zero(lds, img_lo, img_hi, lane);
@@ -305,11 +338,18 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
         slot0[it] = (hash_code(cin[it].code) >> 7) & a.table_mask;
         te[it].type = 0;
         te[it].code = 0;
-        if (lane + 64 * it < n_listed) te[it] = a.table[slot0[it]];
+        if (lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) te[it] = a.table[slot0[it]];
+        if (YGO_SKIP & 64) {  // priced without the table read: a made-up known card
+          te[it].code = cin[it].code;
+          te[it].type = kEntryValid | 1u | (1u << (4 + (cin[it].code & 7)));
+          te[it].card_id = (uint16_t)cin[it].code;
+          te[it].level = 4; te[it].attr_id = 1; te[it].race_id = 1;
+        }
       }
       wave_fence();  // staging area consumed
       wave_zero(lds, img_lo, img_hi, lane);
       wave_fence();
+    YGO_STAMP(1);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {  // collisions (load factor <= 0.5): keep probing, rarely
         if ((te[it].type & kEntryValid) && te[it].code != cin[it].code) {
@@ -327,15 +367,15 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
           slot0[it] = slot;
         }
       }
-      YGO_STAMP(0);
 
+      YGO_STAMP(2);
       // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
       // written: the image starts zeroed. Every listed row also enters the env's direct-mapped
       // spec table (the reference's per-step spec2index hash map, :1549). ----
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int k = lane + 64 * it;
-        if (k < n_listed) {
+        if (k < n_listed && !(YGO_SKIP & 1)) {
           // segment of card k: the last listed segment starting at or before k
           int s = 0, s_row = seg_row[0], s_card = seg_card[0], s_cnt = seg_cnt[0];
 #pragma unroll
@@ -414,17 +454,16 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
           }
       }
       wave_fence();
-      YGO_STAMP(1);
+      YGO_STAMP(3);
       // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
       // one of them, the reference the LAST one; detect it and take the exact scan instead
       bool dup = false;
-      for (int k = lane; k < n_listed; k += 64) {
+      for (int k = lane; k < n_listed && !(YGO_SKIP & 2); k += 64) {
         const uint32_t key = my_rowkey[k];
         const int ti = key == 0xffffffffu ? -1 : spec_slot(key, a.max_cards);
         if (ti >= 0 && my_spec[ti] != my_krow[k]) dup = true;
       }
       dup = __any(dup);
-      YGO_STAMP(2);
       // ---- obs:global_ (:1605-1620) ----
       if (lane == 0) {
         ft(lp_me, my_global[0], my_global[1]);
@@ -435,7 +474,7 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
         my_global[6] = to_play == turn_player ? 1 : 0;
       }
       // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
-      {
+      if (!(YGO_SKIP & 4)) {
         const int shift = ha_p * nf;
 #pragma unroll
         for (int ww = 0; ww < 2; ++ww) {
@@ -456,9 +495,9 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
           my_hact[dst] = (rec + a.off_hist)[src];
         }
       }
-      YGO_STAMP(3);
+      YGO_STAMP(4);
       // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
-      if (lane < n_opt) {
+      if (lane < n_opt && !(YGO_SKIP & 8)) {
         uint8_t* arow = my_actions + lane * nf;
         const int ns = min((int)mine.n_specs, a.mms);
         bool open = true;
@@ -490,8 +529,8 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
         for (int k = 0; k < 9; ++k)
           if (mine.feats[k]) arow[2 * a.mms + k] = mine.feats[k];
       }
-      YGO_STAMP(4);
     }
+    YGO_STAMP(5);
     // ---- scalars + Env::Allocate common fields (env.h:196-222) ----
     if (lane == 0) {
       a.out.env_id[e] = env_id;
@@ -508,30 +547,17 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
       a.out.win_reason[e] = (int)w[7];
     }
     if (__any(bad) && lane == 0) *a.err = 1u;
-  }
-  YGO_STAMP(5);
-  __syncthreads();
-  YGO_STAMP(6);
+    wave_fence();
 
-  // ---- write the group's images: 16-byte-per-lane coalesced stores ----
-  auto flush = [&](uint8_t* gbase, const uint8_t* lbase, int64_t per_env) {
-    const int64_t bytes = per_env * gvalid;
-    uint8_t* g = gbase + e0 * per_env;  // 16-byte aligned whenever 8*per_env is
-    if (((uintptr_t)g & 15) == 0) {
-      const int64_t nvec = bytes >> 4;
-      for (int64_t q = tid; q < nvec; q += kThreads)
-        reinterpret_cast<uint4*>(g)[q] = reinterpret_cast<const uint4*>(lbase)[q];
-      for (int64_t b = (nvec << 4) + tid; b < bytes; b += kThreads) g[b] = lbase[b];
-    } else {
-      for (int64_t b = tid; b < bytes; b += kThreads) g[b] = lbase[b];
-    }
-  };
-  flush(a.out.cards, lds + cv.cards, (int64_t)R * 39);
-  flush(a.out.actions, lds + cv.actions, (int64_t)a.max_options * nf);
-  flush(a.out.h_actions, lds + cv.hact, (int64_t)a.n_hist * nf);
-  flush(a.out.global, lds + cv.global, 8);
-  flush(reinterpret_cast<uint8_t*>(a.out.h_card_ids), lds + cv.hcids, (int64_t)a.max_options * a.mms * 2);
-  YGO_STAMP(7);
+    YGO_STAMP(6);
+    // ---- the env's images leave the CU: aligned 16-byte-per-lane stores for the bulk ----
+    if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, img_lo, R * 39, lane);
+    wave_flush(g_actions, lds, act_lo, a.max_options * nf, lane);
+    wave_flush(g_hact, lds, hact_lo, hist_bytes, lane);
+    wave_flush(g_hcids, lds, hcids_lo, a.max_options * a.mms * 2, lane);
+    if (lane < 8) a.out.global[e * 8 + lane] = my_global[lane];
+    YGO_STAMP(7);
+  }
 }
 
 }  // namespace ygk
