@@ -50,25 +50,14 @@ struct Outs {
   int32_t* num_options; int32_t* to_play; int32_t* is_selfplay; int32_t* win_reason; uint16_t* h_card_ids;
 };
 
-struct Args {
-  const uint8_t* records;
-  int64_t stride;
-  int32_t n;
-  const HashEntry* table;
-  const HashAux* table_aux;
-  uint32_t table_mask;  // capacity - 1
-  int32_t max_cards, max_options, n_hist, mms, nf, max_episode_steps;
-  int32_t off_hist, off_cards, off_opts;  // byte offsets inside a record
-  Outs out;
-  uint32_t* err;  // host-mapped error word of this batch
-  unsigned long long* stamps;  // diagnostic builds only (-DYGO_STAMPS): cycles per phase
-};
-
 __host__ __device__ inline int al16(int x) { return (x + 15) & ~15; }
 // per-wave LDS arena (byte offsets inside it, all 16-byte aligned). Each image region has 16
 // spare bytes so that the image can start at its destination's address modulo 16.
 struct Carve {
-  int cards, actions, hact, global, hcids, spec, rowkey, wave_stride, total, spec_stride, rowkey_stride;
+  int cards, actions, hact, global, hcids, spec, rowkey, stage, wave_stride, total, spec_stride, rowkey_stride;
+  int zero_bytes;                               // [cards, rowkey) starts every env as zeros
+  int off_hist, off_cards, off_opts, rec_bytes; // record layout (include/envpool_amd_ygo.h)
+  int stage_bytes;                              // rec_bytes rounded up to whole 1 KiB LDS-DMA instructions
 };
 // direct-mapped spec table of one env: [2 players][7 locations][max_cards sequences] plus
 // [2][8 monster zones][8 overlay letters], one byte each (1-based row index, 0 = absent)
@@ -76,6 +65,11 @@ __host__ __device__ inline int spec_table_bytes(int max_cards) { return al16(14 
 __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_hist, int mms) {
   const int nf = 9 + 2 * mms, R = 2 * max_cards;
   Carve c;
+  c.off_hist = 64;
+  c.off_cards = c.off_hist + al16(n_hist * nf);
+  c.off_opts = al16(c.off_cards + R * (int)sizeof(ygo_card));
+  c.rec_bytes = al16(c.off_opts + max_options * (int)sizeof(ygo_option));
+  c.stage_bytes = (c.rec_bytes + 1023) & ~1023;
   int o = 0;
   c.cards = o;   o += al16(R * 39) + 16;
   c.actions = o; o += al16(max_options * nf) + 16;
@@ -84,18 +78,28 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.global = o;  o += 16;
   c.spec_stride = spec_table_bytes(max_cards);
   c.spec = o;    o += c.spec_stride;
+  c.zero_bytes = o;
   c.rowkey_stride = al16(R * 4 + R);  // key of listed card k (u32), then its row (u8)
   c.rowkey = o;  o += c.rowkey_stride;
+  c.stage = o;   o += c.stage_bytes;  // the NEXT env's record lands here by LDS-DMA
   c.wave_stride = o;
   c.total = o * kGroup;
   return c;
 }
-// staging of one env's ygo_card / ygo_option arrays inside its own (not yet used) card image
-__host__ __device__ inline int card_chunks(int max_cards) { return (2 * max_cards * (int)sizeof(ygo_card) + 15) >> 4; }
-__host__ __device__ inline int opt_chunks(int max_options) { return (max_options * (int)sizeof(ygo_option) + 15) >> 4; }
-__host__ __device__ inline bool stage_fits(int max_cards, int max_options) {
-  return (card_chunks(max_cards) + opt_chunks(max_options)) * 16 + 15 <= 2 * max_cards * 39;
-}
+
+struct Args {
+  const uint8_t* records;
+  int64_t stride;
+  int32_t n;
+  const HashEntry* table;
+  const HashAux* table_aux;
+  uint32_t table_mask;  // capacity - 1
+  int32_t max_cards, max_options, n_hist, mms, nf, max_episode_steps;
+  Carve cv;  // LDS arena and record layout, computed once on the host
+  Outs out;
+  uint32_t* err;  // host-mapped error word of this batch
+  unsigned long long* stamps;  // diagnostic builds only (-DYGO_STAMPS): cycles per phase
+};
 
 __device__ __forceinline__ void ft(int x, uint8_t& hi, uint8_t& lo) {  // float_transform :704-710
   x = x % 65536;
@@ -155,14 +159,30 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// zero the LDS bytes [lo, hi) with one wave: 16-byte stores for the aligned middle
-__device__ __forceinline__ void wave_zero(unsigned char* lds, int lo, int hi, int lane) {
-  const int mlo = min((lo + 15) & ~15, hi), mhi = max(hi & ~15, mlo);
-  if (lane < mlo - lo) lds[lo + lane] = 0;
-  if (lane < hi - mhi) lds[mhi + lane] = 0;
+// zero the 16-byte aligned LDS span [lo, lo+bytes) with one wave
+__device__ __forceinline__ void wave_zero16(unsigned char* lds, int lo, int bytes, int lane) {
   const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int q = (mlo >> 4) + lane; q < (mhi >> 4); q += 64) reinterpret_cast<uint4*>(lds)[q] = z;
+  for (int q = lane; q < (bytes >> 4); q += 64) reinterpret_cast<uint4*>(lds + lo)[q] = z;
 }
+
+// One LDS-DMA instruction: every lane copies 16 bytes from its `gsrc` to lds_base + lane*16 (1 KiB
+// per wave instruction, no VGPR round trip). M0 carries the wave-uniform LDS base and is
+// compiler-reserved, so it is saved and restored inside the statement
+// (cdna_hip_programming.md section 5.7). The compiler does not see these loads: the waits for
+// them are the explicit vm_wait below.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
 
 // copy the LDS bytes [lo, lo+bytes) to g with one wave. When g and lo agree modulo 16 the bulk
 // goes as aligned 16-byte stores; otherwise (odd-aligned caller buffers) byte by byte.
@@ -185,73 +205,72 @@ __device__ __forceinline__ uint32_t lane_word(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
 
-__global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
+__global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  const Carve cv = carve(a.max_cards, a.max_options, a.n_hist, a.mms);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const Carve& cv = a.cv;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it
 #ifdef YGO_STAMPS
   unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
   const int R = 2 * a.max_cards, nf = a.nf;
-  const int64_t e0 = (int64_t)blockIdx.x * kGroup;
-  const int gvalid = (int)min((int64_t)kGroup, (int64_t)a.n - e0);
-  const int64_t e = e0 + wave;
-  bool bad = false;
+  const int hist_bytes = a.n_hist * nf;
+  // persistent waves: wave g encodes envs g, g + W, g + 2W, ... one after the other, and the
+  // record of its next env travels HBM -> LDS (LDS-DMA) underneath the encode of the current one
+  const int64_t n_waves = (int64_t)gridDim.x * kGroup;
+  int64_t e = (int64_t)blockIdx.x * kGroup + wave;
+  if (e >= a.n) return;  // wave-uniform; no workgroup barrier anywhere in this kernel
 
-  if (wave < gvalid) {  // wave-uniform: one wave64 encodes one env, with no cross-wave traffic
-    const uint8_t* rec = a.records + e * a.stride;
-    const int arena = wave * cv.wave_stride;
+  const int arena = wave * cv.wave_stride;
+  uint8_t* const my_global = lds + arena + cv.global;
+  uint32_t* const my_rowkey = reinterpret_cast<uint32_t*>(lds + arena + cv.rowkey);
+  uint8_t* const my_krow = reinterpret_cast<uint8_t*>(my_rowkey + R);
+  uint8_t* const my_spec = lds + arena + cv.spec;
+  const uint8_t* const stage = lds + arena + cv.stage;
+  const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
+  const int n_chunks = cv.rec_bytes >> 4, n_dma = cv.stage_bytes >> 10;
+  // lower bound on the VMEM stores one env issues after its prefetch (obs:global_, one each for
+  // obs:actions_/h_actions_/h_card_ids, the full 1 KiB rounds of obs:cards_): that many youngest
+  // operations may stay in flight when the next iteration waits for the prefetched record
+  // (VMEM retires in issue order)
+  const int young = 4 + ((R * 39 - 15) >> 10);
+
+  auto fetch = [&](int64_t env) {
+    const uint8_t* g = a.records + env * a.stride;
+    lds_drain();  // every earlier LDS read of the stage has returned
+    for (int c = 0; c < n_dma; ++c) {
+      const int chunk = min(lane0 + 64 * c, n_chunks - 1);  // the pad lanes re-read the last chunk
+      dma16(g + (int64_t)chunk * 16, stage_lds + 1024u * (uint32_t)c);
+    }
+  };
+  fetch(e);
+  bool first = true;
+
+  for (; e < a.n; e += n_waves) {
+    // the lane id is made opaque per iteration: otherwise every lane-dependent address and
+    // predicate of the body is hoisted out of the loop and held in VGPRs (240 of them)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    bool bad = false;
     // global destinations of this env's images, and LDS offsets congruent to them modulo 16
     uint8_t* g_cards = a.out.cards + e * (int64_t)(R * 39);
-    uint8_t* g_actions = a.out.actions + e * (int64_t)(a.max_options * nf);
-    uint8_t* g_hact = a.out.h_actions + e * (int64_t)(a.n_hist * nf);
-    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
-    const int img_lo = arena + cv.cards + (int)((uintptr_t)g_cards & 15), img_hi = img_lo + R * 39;
-    const int act_lo = arena + cv.actions + (int)((uintptr_t)g_actions & 15);
-    const int hact_lo = arena + cv.hact + (int)((uintptr_t)g_hact & 15);
-    const int hcids_lo = arena + cv.hcids + (int)((uintptr_t)g_hcids & 14);  // keep uint16 alignment
+    const int img_lo = arena + cv.cards + (int)((uintptr_t)g_cards & 15);
     uint8_t* my_cards = lds + img_lo;
-    uint8_t* my_actions = lds + act_lo;
-    uint8_t* my_hact = lds + hact_lo;
-    uint8_t* my_global = lds + arena + cv.global;
-    uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + hcids_lo);
-    uint32_t* my_rowkey = reinterpret_cast<uint32_t*>(lds + arena + cv.rowkey);
-    uint8_t* my_krow = reinterpret_cast<uint8_t*>(my_rowkey + R);
-    uint8_t* my_spec = lds + arena + cv.spec;
 
-    // ---- every global read of this env is issued up front as 16-byte-per-lane coalesced loads
-    // (the record layout is fixed, so no address depends on the header): header, the ygo_card
-    // array, the ygo_option array, the history ring ----
-    const bool staged = stage_fits(a.max_cards, a.max_options);
-    const int n_cchunks = card_chunks(a.max_cards), n_ochunks = opt_chunks(a.max_options);
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-    uint4 hq = z4, cq[5] = {z4, z4, z4, z4, z4}, oq[3] = {z4, z4, z4};
-    if (lane < 4) hq = reinterpret_cast<const uint4*>(rec)[lane];
-    if (staged) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        if (lane + 64 * c < n_cchunks) cq[c] = reinterpret_cast<const uint4*>(rec + a.off_cards)[lane + 64 * c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (lane + 64 * c < n_ochunks) oq[c] = reinterpret_cast<const uint4*>(rec + a.off_opts)[lane + 64 * c];
-    }
-    const int hist_bytes = a.n_hist * nf;
-    uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
-    {
-      const uint32_t* ring_w = reinterpret_cast<const uint32_t*>(rec + a.off_hist);
-      if (4 * lane < hist_bytes) hw[0] = ring_w[lane];
-      if (256 + 4 * lane < hist_bytes) hw[1] = ring_w[64 + lane];
-    }
+    // ---- all images and the spec table start as zeros (the reference's fresh zero-filled
+    // StateBuffer, array.h:77-81), while the record is still on its way ----
+    wave_zero16(lds, arena + cv.cards, cv.zero_bytes, lane);
 
-    // ---- while they fly: the env's small images start as zeros (the reference's fresh
-    // zero-filled StateBuffer, array.h:77-81) ----
-    wave_zero(lds, act_lo, act_lo + a.max_options * nf, lane);
-    wave_zero(lds, hact_lo, hact_lo + hist_bytes, lane);
-    wave_zero(lds, hcids_lo, hcids_lo + a.max_options * a.mms * 2, lane);
-    wave_zero(lds, arena + cv.spec, arena + cv.spec + cv.spec_stride, lane);
-    if (lane < 2) reinterpret_cast<uint32_t*>(my_global)[lane] = 0u;
+    // ---- the record of this env is in the stage once the DMA issued one env ago has landed ----
+    if (first || young < 4) vm_wait<0>();
+    else if (young < 8) vm_wait<4>();
+    else if (young < 16) vm_wait<8>();
+    else vm_wait<16>();
+    first = false;
+    wave_fence();
 
-    // ---- header: lanes 0..3 hold it; every field becomes a wave-uniform scalar ----
+    // ---- header: every field becomes a wave-uniform scalar ----
+    const uint4 hq = reinterpret_cast<const uint4*>(stage)[lane & 3];
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -260,133 +279,217 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
       w[4 * i + 2] = lane_word(hq.z, i);
       w[4 * i + 3] = lane_word(hq.w, i);
     }
-    const int to_play = w[0] & 0xff, turn_player = (w[0] >> 8) & 0xff;
+    const int to_play = w[0] & 0xff;
     int n_opt = w[0] >> 24;
-    const int is_selfplay = w[1] & 0xff, ha_p = (w[1] >> 16) & 0xff;
-    const bool revealed_any = ((w[1] >> 8) & 0xff) != 0, done = (w[1] >> 24) != 0;
-    const int env_id = (int)w[2], elapsed = (int)w[3];
-    const int lp_me = (int)(to_play == 0 ? w[4] : w[5]), lp_op = (int)(to_play == 0 ? w[5] : w[4]);
-    const uint32_t phase = w[6];
+    const int ha_p = (w[1] >> 16) & 0xff;
+    const bool revealed_any = ((w[1] >> 8) & 0xff) != 0;
     const uint64_t hand_mask = (uint64_t)w[10] | ((uint64_t)w[11] << 32);
     const bool no_options = n_opt == 0;                // early-out of WriteState (:1837-1841)
     if (n_opt > a.max_options) n_opt = a.max_options;  // options_.resize (:1849-1851)
 
-    // ---- segment table: 2 players x 7 locations (:1510-1519), all scalar ----
-    int seg_row[14], seg_card[14], seg_cnt[14], rows_pi[2], n_cards = 0;
+    // ---- segments: 2 players x 7 locations (:1510-1519), walked with scalar counters. Each lane
+    // picks up, for its cards k = lane + 64*it, the last listed segment starting at or before k:
+    // packed as row delta (r - k, bits 0..12, biased by 4096) | segment << 13 | "fits" << 17.
+    // Hidden opponent locations get their placeholder rows {col2 = location id, col4 = 1}
+    // (:1526-1532) on the spot. ----
+    int n_cards = 0;
+    uint32_t segv[4] = {0, 0, 0, 0};
+    if (!no_options) {
 #pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      int row = pi * a.max_cards;
+      for (int pi = 0; pi < 2; ++pi) {
+        int row = pi * a.max_cards;
 #pragma unroll
-      for (int li = 0; li < 7; ++li) {
-        const int s = pi * 7 + li;
-        const int cnt = (int)((w[12 + (s >> 2)] >> (8 * (s & 3))) & 0xff);
-        bool hidden = (li == 0 || li == 1 || li == 6);
-        if (li == 1 && revealed_any) hidden = false;  // :1522-1525
-        const bool count_only = pi == 1 && hidden;
-        seg_row[s] = row;
-        seg_card[s] = count_only ? 0x7fffffff : n_cards;  // count-only: never matches a card index
-        seg_cnt[s] = cnt;
-        row += cnt;
-        if (!count_only) n_cards += cnt;
+        for (int li = 0; li < 7; ++li) {
+          const int s = pi * 7 + li;
+          const int cnt = (int)((w[12 + (s >> 2)] >> (8 * (s & 3))) & 0xff);
+          bool hidden = (li == 0 || li == 1 || li == 6);
+          if (li == 1 && revealed_any) hidden = false;  // :1522-1525
+          const bool count_only = pi == 1 && hidden;
+          // the reference has no bound; more rows than max_cards is a buffer overrun there: such a
+          // segment is left out and the batch is flagged
+          const bool fits = row + cnt <= (pi + 1) * a.max_cards;
+          if (!fits) bad = true;
+          if (cnt > 0) {
+            if (count_only) {
+              if (fits)
+                for (int q = lane; q < cnt; q += 64) {
+                  uint8_t* prow = my_cards + (row + q) * 39;
+                  prow[2] = (uint8_t)(li + 1);
+                  prow[4] = 1;
+                }
+            } else {
+              const uint32_t packed = (uint32_t)(row - n_cards + 4096) | ((uint32_t)s << 13) | ((uint32_t)fits << 17);
+#pragma unroll
+              for (int it = 0; it < 4; ++it)
+                if (lane + 64 * it >= n_cards) segv[it] = packed;
+              n_cards += cnt;
+            }
+          }
+          row += cnt;
+        }
       }
-      // the reference has no bound; more rows than max_cards is a buffer overrun there
-      if (row > (pi + 1) * a.max_cards) bad = true;
-      rows_pi[pi] = row - pi * a.max_cards;
     }
     const int n_listed = min(n_cards, R);
-    const bool overflow = rows_pi[0] > a.max_cards || rows_pi[1] > a.max_cards;
     YGO_STAMP(0);
+    const int64_t e_next = e + n_waves;
+
+    // ---- scalars + Env::Allocate common fields (env.h:196-222), obs:global_ (:1605-1620) ----
+    if (lane == 0) {
+      const bool done = (w[1] >> 24) != 0;
+      const int elapsed = (int)w[3];
+      a.out.env_id[e] = (int)w[2];
+      a.out.penv[e] = (int)w[2];
+      a.out.elapsed[e] = elapsed;
+      a.out.done[e] = done;
+      a.out.reward[e] = __uint_as_float(w[8]);
+      a.out.discount[e] = done ? 0.f : 1.f;
+      a.out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
+      a.out.trunc[e] = done && (elapsed >= a.max_episode_steps);
+      a.out.num_options[e] = no_options ? 1 : n_opt;
+      a.out.to_play[e] = to_play;
+      a.out.is_selfplay[e] = (int)(w[1] & 0xff);
+      a.out.win_reason[e] = (int)w[7];
+      if (no_options) {
+        my_global[7] = 1;  // :1839
+      } else {
+        const int turn_player = (w[0] >> 8) & 0xff;
+        const uint32_t phase = w[6];
+        ft((int)(to_play == 0 ? w[4] : w[5]), my_global[0], my_global[1]);
+        ft((int)(to_play == 0 ? w[5] : w[4]), my_global[2], my_global[3]);
+        if (phase == 0 || (phase & (phase - 1)) != 0 || phase > 0x200) bad = true;
+        else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
+        my_global[5] = to_play == 0 ? 1 : 0;
+        my_global[6] = to_play == turn_player ? 1 : 0;
+      }
+    }
 
     if (no_options) {
-      wave_zero(lds, img_lo, img_hi, lane);
-      if (lane == 0) my_global[7] = 1;  // :1839
+      wave_fence();
+      if (e_next < a.n) fetch(e_next);
     } else {
-      // ---- hand the card / option arrays to their owning lanes: lane l owns cards l, l+64,
-      // l+128, l+192 and option l. The env's own card image region is the staging area. ----
-      ygo_card cin[4];
-      ygo_option mine;
-      mine.n_specs = 0;
-      if (staged) {
-        uint8_t* stage = lds + ((img_lo + 15) & ~15);
-#pragma unroll
-        for (int c = 0; c < 5; ++c)
-          if (lane + 64 * c < n_cchunks) reinterpret_cast<uint4*>(stage)[lane + 64 * c] = cq[c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          if (lane + 64 * c < n_ochunks) reinterpret_cast<uint4*>(stage + n_cchunks * 16)[lane + 64 * c] = oq[c];
-        wave_fence();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          cin[it].code = 0;
-          if (lane + 64 * it < n_listed) cin[it] = reinterpret_cast<const ygo_card*>(stage)[lane + 64 * it];
-        }
-        if (lane < n_opt) mine = reinterpret_cast<const ygo_option*>(stage + n_cchunks * 16)[lane];
-      } else {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          cin[it].code = 0;
-          if (lane + 64 * it < n_listed) cin[it] = reinterpret_cast<const ygo_card*>(rec + a.off_cards)[lane + 64 * it];
-        }
-        if (lane < n_opt) mine = reinterpret_cast<const ygo_option*>(rec + a.off_opts)[lane];
-      }
-      // ---- static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's
-      // cards are in flight together, and the image is zeroed underneath them. ----
-      HashEntry te[4];
-      uint32_t slot0[4];
+      uint8_t* g_actions0 = a.out.actions + e * (int64_t)(a.max_options * nf);
+      uint8_t* g_hact0 = a.out.h_actions + e * (int64_t)hist_bytes;
+      uint8_t* g_hcids0 = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
+      uint8_t* my_actions = lds + arena + cv.actions + (int)((uintptr_t)g_actions0 & 15);
+      uint8_t* my_hact = lds + arena + cv.hact + (int)((uintptr_t)g_hact0 & 15);
+      uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((uintptr_t)g_hcids0 & 14));
+      // ---- the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128,
+      // l+192 and option l; the history ring is held four bytes per lane. They stay PACKED (raw
+      // dwords) until the code that needs a field: unpacked early they cost 60 more VGPRs. ----
+      uint32_t cw[4][5];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack | defense
+      uint32_t mw[11];     // ygo_option: feats[0..8], n_specs, pad | spec_key[8]
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        slot0[it] = (hash_code(cin[it].code) >> 7) & a.table_mask;
-        te[it].type = 0;
-        te[it].code = 0;
-        if (lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) te[it] = a.table[slot0[it]];
-        if (YGO_SKIP & 64) {  // priced without the table read: a made-up known card
-          te[it].code = cin[it].code;
-          te[it].type = kEntryValid | 1u | (1u << (4 + (cin[it].code & 7)));
-          te[it].card_id = (uint16_t)cin[it].code;
-          te[it].level = 4; te[it].attr_id = 1; te[it].race_id = 1;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) cw[it][d] = 0;
+        if (lane + 64 * it < n_listed) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + (lane + 64 * it) * 5;
+#pragma unroll
+          for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
         }
       }
-      wave_fence();  // staging area consumed
-      wave_zero(lds, img_lo, img_hi, lane);
-      wave_fence();
-    YGO_STAMP(1);
+#pragma unroll
+      for (int d = 0; d < 11; ++d) mw[d] = 0;
+      if (lane < n_opt) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + lane * 11;
+#pragma unroll
+        for (int d = 0; d < 11; ++d) mw[d] = src[d];
+      }
+      uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
+      {
+        const uint32_t* ring_w = reinterpret_cast<const uint32_t*>(stage + cv.off_hist);
+        if (4 * lane < hist_bytes) hw[0] = ring_w[lane];
+        if (256 + 4 * lane < hist_bytes) hw[1] = ring_w[64 + lane];
+      }
+      // ---- static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's
+      // cards are in flight together. An overlay material shows its static attack / defense
+      // (c_get_card copy, :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
+      uint4 tq[4];  // HashEntry: code | type | card_id, level, attr_id | race_id
+      const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
+      // (unconditional loads: a lane without a card probes the slot of code 0, in bounds, and
+      // ignores the answer - a conditional load would make the compiler wait for each in turn)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const uint32_t slot0 = (hash_code(cw[it][0]) >> 7) & a.table_mask;
+        if (!(YGO_SKIP & (32 | 64))) tq[it] = table_q[slot0];
+        if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
+          tq[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
+        if (YGO_SKIP & 32) tq[it] = make_uint4(0, 0, 0, 0);
+      }
+      uint2 ax[4];  // HashAux of the lane's overlay materials
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        ax[it] = make_uint2(0, 0);
+        if ((cw[it][2] >> 24) && !(YGO_SKIP & (32 | 64)))
+          ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[(hash_code(cw[it][0]) >> 7) & a.table_mask];
+      }
+      // rings longer than 512 bytes: the tail goes from the stage to the image now
+      if (hist_bytes > 512) {
+        const int shift = ha_p * nf;
+        for (int src = 512 + lane; src < hist_bytes; src += 64) {
+          int dst = src - shift;
+          if (dst < 0) dst += hist_bytes;
+          my_hact[dst] = (stage + cv.off_hist)[src];
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {  // collisions (load factor <= 0.5): keep probing, rarely
-        if ((te[it].type & kEntryValid) && te[it].code != cin[it].code) {
-          uint32_t slot = slot0[it];
-          HashEntry found;
-          found.type = 0;
-          found.code = 0;
+        if (lane + 64 * it < n_listed && (tq[it].y & kEntryValid) && tq[it].x != cw[it][0]) {
+          uint32_t slot = (hash_code(cw[it][0]) >> 7) & a.table_mask;
+          uint4 found = make_uint4(0, 0, 0, 0);
           for (uint32_t probe = 0; probe < a.table_mask; ++probe) {
             slot = (slot + 1) & a.table_mask;
-            const HashEntry cand = a.table[slot];
-            if (!(cand.type & kEntryValid)) break;
-            if (cand.code == cin[it].code) { found = cand; break; }
+            const uint4 cand = table_q[slot];
+            if (!(cand.y & kEntryValid)) break;
+            if (cand.x == cw[it][0]) { found = cand; break; }
           }
-          te[it] = found;
-          slot0[it] = slot;
+          tq[it] = found;
+          if (cw[it][2] >> 24) ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[slot];
         }
       }
-
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (cw[it][2] >> 24) {
+          cw[it][3] = ax[it].x;
+          cw[it][4] = ax[it].y;
+        }
+      // every table read has returned (make the compiler settle them here: a wait for one of
+      // them after the prefetch below would also wait for the prefetch)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
+      YGO_STAMP(1);
+      // ---- the stage is consumed: the next env's record starts its way in ----
+      wave_fence();
+      if (e_next < a.n) fetch(e_next);
       YGO_STAMP(2);
+
       // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
       // written: the image starts zeroed. Every listed row also enters the env's direct-mapped
       // spec table (the reference's per-step spec2index hash map, :1549). ----
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
+        // one card at a time, unpacked here and no earlier
+        asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
         const int k = lane + 64 * it;
         if (k < n_listed && !(YGO_SKIP & 1)) {
-          // segment of card k: the last listed segment starting at or before k
-          int s = 0, s_row = seg_row[0], s_card = seg_card[0], s_cnt = seg_cnt[0];
-#pragma unroll
-          for (int ss = 1; ss < 14; ++ss)
-            if (k >= seg_card[ss]) { s = ss; s_row = seg_row[ss]; s_card = seg_card[ss]; s_cnt = seg_cnt[ss]; }
+          const uint32_t sv = segv[it];
+          const int s = (sv >> 13) & 15;
           const int pi = s >= 7 ? 1 : 0, li = s - 7 * pi;
-          const int r = s_row + (k - s_card);
+          const int r = k + (int)(sv & 8191) - 4096;
           uint32_t key = 0xffffffffu;
-          if (!overflow || s_row + s_cnt <= (pi + 1) * a.max_cards) {
-            const ygo_card c = cin[it];
-            const HashEntry t = te[it];
+          if (sv & (1u << 17)) {
+            ygo_card c;
+            c.code = cw[it][0];
+            c.controller = (uint8_t)cw[it][1]; c.location = (uint8_t)(cw[it][1] >> 8);
+            c.sequence = (uint8_t)(cw[it][1] >> 16); c.position = (uint8_t)(cw[it][1] >> 24);
+            c.level = (uint8_t)cw[it][2]; c.rank = (uint8_t)(cw[it][2] >> 8);
+            c.link = (uint8_t)(cw[it][2] >> 16); c.is_material = (uint8_t)(cw[it][2] >> 24);
+            c.attack = (int32_t)cw[it][3]; c.defense = (int32_t)cw[it][4];
+            HashEntry t;
+            t.code = tq[it].x; t.type = tq[it].y;
+            t.card_id = (uint16_t)tq[it].z; t.level = (uint8_t)(tq[it].z >> 16); t.attr_id = (uint8_t)(tq[it].z >> 24);
+            t.race_id = (uint8_t)tq[it].w;
             const bool known = (t.type & kEntryValid) && t.code == c.code;
             uint8_t* row = my_cards + r * 39;
             const uint32_t loc7 = c.location & 0x7f;
@@ -414,11 +517,7 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
               row[7] = t.attr_id == 0xff ? 0 : t.attr_id;
               row[8] = t.race_id == 0xff ? 0 : t.race_id;
               int level = t.level, atk = c.attack, def = c.defense;
-              if (c.is_material) {  // an overlay material shows its static values (c_get_card copy, :2109-2114)
-                const HashAux x = a.table_aux[slot0[it]];
-                atk = x.attack;
-                def = x.defense;
-              } else {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
+              if (!c.is_material) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
                 if (c.level > 0) level = c.level;
                 if (c.rank > 0) level = c.rank;
                 if (c.link > 0) level = c.link;
@@ -442,17 +541,6 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
           my_rowkey[k] = key;
         }
       }
-      // hidden opponent locations: placeholder rows {col2 = location id, col4 = 1} (:1526-1532)
-#pragma unroll
-      for (int li = 0; li < 7; li += (li == 1 ? 5 : 1)) {  // DECK, HAND, EXTRA
-        const int s = 7 + li;
-        if (seg_card[s] == 0x7fffffff && seg_row[s] + seg_cnt[s] <= 2 * a.max_cards)
-          for (int q = lane; q < seg_cnt[s]; q += 64) {
-            uint8_t* row = my_cards + (seg_row[s] + q) * 39;
-            row[2] = (uint8_t)(li + 1);
-            row[4] = 1;
-          }
-      }
       wave_fence();
       YGO_STAMP(3);
       // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
@@ -464,15 +552,6 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
         if (ti >= 0 && my_spec[ti] != my_krow[k]) dup = true;
       }
       dup = __any(dup);
-      // ---- obs:global_ (:1605-1620) ----
-      if (lane == 0) {
-        ft(lp_me, my_global[0], my_global[1]);
-        ft(lp_op, my_global[2], my_global[3]);
-        if (phase == 0 || (phase & (phase - 1)) != 0 || phase > 0x200) bad = true;
-        else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
-        my_global[5] = to_play == 0 ? 1 : 0;
-        my_global[6] = to_play == turn_player ? 1 : 0;
-      }
       // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
       if (!(YGO_SKIP & 4)) {
         const int shift = ha_p * nf;
@@ -489,22 +568,19 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
             }
           }
         }
-        for (int src = 512 + lane; src < hist_bytes; src += 64) {  // rings longer than 512 bytes
-          int dst = src - shift;
-          if (dst < 0) dst += hist_bytes;
-          my_hact[dst] = (rec + a.off_hist)[src];
-        }
       }
       YGO_STAMP(4);
       // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
+#pragma unroll
+      for (int d = 0; d < 11; ++d) asm volatile("" : "+v"(mw[d]));
       if (lane < n_opt && !(YGO_SKIP & 8)) {
         uint8_t* arow = my_actions + lane * nf;
-        const int ns = min((int)mine.n_specs, a.mms);
+        const int ns = min((int)((mw[2] >> 8) & 0xff), a.mms);
         bool open = true;
 #pragma unroll
         for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
           if (j < ns) {
-            const uint32_t key = mine.spec_key[j];
+            const uint32_t key = mw[3 + j];
             const int ti = spec_slot(key, a.max_cards);
             int idx = 0;
             if (ti >= 0 && !dup) {
@@ -526,37 +602,29 @@ __global__ __launch_bounds__(kThreads, 4) void ygo_encode(Args a) {
           }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-          if (mine.feats[k]) arow[2 * a.mms + k] = mine.feats[k];
+        for (int k = 0; k < 9; ++k) {
+          const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
+          if (f) arow[2 * a.mms + k] = f;
+        }
       }
     }
     YGO_STAMP(5);
-    // ---- scalars + Env::Allocate common fields (env.h:196-222) ----
-    if (lane == 0) {
-      a.out.env_id[e] = env_id;
-      a.out.penv[e] = env_id;
-      a.out.elapsed[e] = elapsed;
-      a.out.done[e] = done;
-      a.out.reward[e] = __uint_as_float(w[8]);
-      a.out.discount[e] = done ? 0.f : 1.f;
-      a.out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
-      a.out.trunc[e] = done && (elapsed >= a.max_episode_steps);
-      a.out.num_options[e] = no_options ? 1 : n_opt;
-      a.out.to_play[e] = to_play;
-      a.out.is_selfplay[e] = is_selfplay;
-      a.out.win_reason[e] = (int)w[7];
-    }
     if (__any(bad) && lane == 0) *a.err = 1u;
     wave_fence();
 
-    YGO_STAMP(6);
     // ---- the env's images leave the CU: aligned 16-byte-per-lane stores for the bulk ----
-    if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, img_lo, R * 39, lane);
-    wave_flush(g_actions, lds, act_lo, a.max_options * nf, lane);
-    wave_flush(g_hact, lds, hact_lo, hist_bytes, lane);
-    wave_flush(g_hcids, lds, hcids_lo, a.max_options * a.mms * 2, lane);
-    if (lane < 8) a.out.global[e * 8 + lane] = my_global[lane];
-    YGO_STAMP(7);
+    {
+      uint8_t* g_actions = a.out.actions + e * (int64_t)(a.max_options * nf);
+      uint8_t* g_hact = a.out.h_actions + e * (int64_t)hist_bytes;
+      uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
+      if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, img_lo, R * 39, lane);
+      wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
+      wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
+      wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
+      if (lane < 8) a.out.global[e * 8 + lane] = my_global[lane];
+    }
+    wave_fence();  // the images are read out before the next env zeroes them
+    YGO_STAMP(6);
   }
 }
 
