@@ -150,6 +150,7 @@ __device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
 #else
 #define YGO_STAMP(k) do {} while (0)
 #endif
+#define YGO_STAMP_END(k) do { const int lane = lane0; YGO_STAMP(k); } while (0)
 
 // LDS traffic of one wave is executed in issue order; the fences keep the compiler from moving
 // accesses of different lanes' data across the hand-over points.
@@ -229,12 +230,6 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
   const int n_chunks = cv.rec_bytes >> 4, n_dma = cv.stage_bytes >> 10;
-  // lower bound on the VMEM stores one env issues after its prefetch (obs:global_, one each for
-  // obs:actions_/h_actions_/h_card_ids, the full 1 KiB rounds of obs:cards_): that many youngest
-  // operations may stay in flight when the next iteration waits for the prefetched record
-  // (VMEM retires in issue order)
-  const int young = 4 + ((R * 39 - 15) >> 10);
-
   auto fetch = [&](int64_t env) {
     const uint8_t* g = a.records + env * a.stride;
     lds_drain();  // every earlier LDS read of the stage has returned
@@ -244,32 +239,51 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     }
   };
   fetch(e);
-  bool first = true;
 
+  // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
+  auto flush_env = [&](int64_t env, int lane) {
+    uint8_t* g_cards = a.out.cards + env * (int64_t)(R * 39);
+    uint8_t* g_actions = a.out.actions + env * (int64_t)(a.max_options * nf);
+    uint8_t* g_hact = a.out.h_actions + env * (int64_t)hist_bytes;
+    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
+    if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
+    wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
+    wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
+    wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
+    if (lane < 8) a.out.global[env * 8 + lane] = my_global[lane];
+  };
+
+  // Per env, in this order (VMEM retires in issue order, and the compiler cannot see the DMA, so
+  // the order is what keeps every wait short):
+  //   A  wait for this env's record (its DMA was issued a whole env ago; nothing younger is pending)
+  //   B  header -> scalars, packed card / option / history words -> lanes, hash probes issued
+  //   C  scalar outputs of this env; the PREVIOUS env's images leave the CU
+  //   D  images zeroed (the reference's fresh zero-filled StateBuffer, array.h:77-81)
+  //   E  placeholder rows, obs:global_
+  //   F  probes settled                       (waits for C's stores too, after D and E)
+  //   G  the next env's record starts its way in (the stage was consumed in B)
+  //   H  rows, options, history: LDS only, a whole phase for the DMA to land
+  int64_t e_prev = -1;
   for (; e < a.n; e += n_waves) {
     // the lane id is made opaque per iteration: otherwise every lane-dependent address and
     // predicate of the body is hoisted out of the loop and held in VGPRs (240 of them)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     bool bad = false;
-    // global destinations of this env's images, and LDS offsets congruent to them modulo 16
     uint8_t* g_cards = a.out.cards + e * (int64_t)(R * 39);
-    const int img_lo = arena + cv.cards + (int)((uintptr_t)g_cards & 15);
-    uint8_t* my_cards = lds + img_lo;
+    uint8_t* my_cards = lds + arena + cv.cards + (int)((uintptr_t)g_cards & 15);
+    uint8_t* g_actions0 = a.out.actions + e * (int64_t)(a.max_options * nf);
+    uint8_t* g_hact0 = a.out.h_actions + e * (int64_t)hist_bytes;
+    uint8_t* g_hcids0 = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
+    uint8_t* my_actions = lds + arena + cv.actions + (int)((uintptr_t)g_actions0 & 15);
+    uint8_t* my_hact = lds + arena + cv.hact + (int)((uintptr_t)g_hact0 & 15);
+    uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((uintptr_t)g_hcids0 & 14));
 
-    // ---- all images and the spec table start as zeros (the reference's fresh zero-filled
-    // StateBuffer, array.h:77-81), while the record is still on its way ----
-    wave_zero16(lds, arena + cv.cards, cv.zero_bytes, lane);
-
-    // ---- the record of this env is in the stage once the DMA issued one env ago has landed ----
-    if (first || young < 4) vm_wait<0>();
-    else if (young < 8) vm_wait<4>();
-    else if (young < 16) vm_wait<8>();
-    else vm_wait<16>();
-    first = false;
+    // ---- A ----
+    vm_wait<0>();
     wave_fence();
 
-    // ---- header: every field becomes a wave-uniform scalar ----
+    // ---- B: header, every field a wave-uniform scalar ----
     const uint4 hq = reinterpret_cast<const uint4*>(stage)[lane & 3];
     uint32_t w[16];
 #pragma unroll
@@ -287,13 +301,13 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     const bool no_options = n_opt == 0;                // early-out of WriteState (:1837-1841)
     if (n_opt > a.max_options) n_opt = a.max_options;  // options_.resize (:1849-1851)
 
-    // ---- segments: 2 players x 7 locations (:1510-1519), walked with scalar counters. Each lane
-    // picks up, for its cards k = lane + 64*it, the last listed segment starting at or before k:
-    // packed as row delta (r - k, bits 0..12, biased by 4096) | segment << 13 | "fits" << 17.
-    // Hidden opponent locations get their placeholder rows {col2 = location id, col4 = 1}
-    // (:1526-1532) on the spot. ----
+    // segments: 2 players x 7 locations (:1510-1519), walked with scalar counters. Each lane picks
+    // up, for its cards k = lane + 64*it, the last listed segment starting at or before k: packed
+    // as row delta (r - k, bits 0..12, biased by 4096) | segment << 13 | "fits" << 17. The three
+    // locations that can be hidden (opponent DECK, HAND, EXTRA) are remembered for step E.
     int n_cards = 0;
     uint32_t segv[4] = {0, 0, 0, 0};
+    int ph_row[3] = {0, 0, 0}, ph_cnt[3] = {0, 0, 0};
     if (!no_options) {
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
@@ -309,31 +323,76 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
           // segment is left out and the batch is flagged
           const bool fits = row + cnt <= (pi + 1) * a.max_cards;
           if (!fits) bad = true;
-          if (cnt > 0) {
-            if (count_only) {
-              if (fits)
-                for (int q = lane; q < cnt; q += 64) {
-                  uint8_t* prow = my_cards + (row + q) * 39;
-                  prow[2] = (uint8_t)(li + 1);
-                  prow[4] = 1;
-                }
-            } else {
-              const uint32_t packed = (uint32_t)(row - n_cards + 4096) | ((uint32_t)s << 13) | ((uint32_t)fits << 17);
+          if (count_only) {
+            const int ph = li == 0 ? 0 : (li == 1 ? 1 : 2);
+            ph_row[ph] = row;
+            ph_cnt[ph] = fits ? cnt : 0;
+          } else if (cnt > 0) {
+            const uint32_t packed = (uint32_t)(row - n_cards + 4096) | ((uint32_t)s << 13) | ((uint32_t)fits << 17);
 #pragma unroll
-              for (int it = 0; it < 4; ++it)
-                if (lane + 64 * it >= n_cards) segv[it] = packed;
-              n_cards += cnt;
-            }
+            for (int it = 0; it < 4; ++it)
+              if (lane + 64 * it >= n_cards) segv[it] = packed;
+            n_cards += cnt;
           }
           row += cnt;
         }
       }
     }
     const int n_listed = min(n_cards, R);
-    YGO_STAMP(0);
-    const int64_t e_next = e + n_waves;
 
-    // ---- scalars + Env::Allocate common fields (env.h:196-222), obs:global_ (:1605-1620) ----
+    // the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128, l+192
+    // and option l; the history ring is held four bytes per lane. They stay PACKED (raw dwords)
+    // until the code that needs a field: unpacked early they cost 60 more VGPRs.
+    uint32_t cw[4][5];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack | defense
+    uint32_t mw[11];     // ygo_option: feats[0..8], n_specs, pad | spec_key[8]
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+      for (int d = 0; d < 5; ++d) cw[it][d] = 0;
+      if (lane + 64 * it < n_listed) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + (lane + 64 * it) * 5;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 11; ++d) mw[d] = 0;
+    if (lane < n_opt) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + lane * 11;
+#pragma unroll
+      for (int d = 0; d < 11; ++d) mw[d] = src[d];
+    }
+    uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
+    {
+      const uint32_t* ring_w = reinterpret_cast<const uint32_t*>(stage + cv.off_hist);
+      if (4 * lane < hist_bytes) hw[0] = ring_w[lane];
+      if (256 + 4 * lane < hist_bytes) hw[1] = ring_w[64 + lane];
+    }
+    // static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's cards are
+    // in flight together. (Unconditional loads: a lane without a card probes the slot of code 0,
+    // in bounds, and ignores the answer - a conditional load would make the compiler wait for
+    // each in turn.) An overlay material shows its static attack / defense (c_get_card copy,
+    // :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
+    uint4 tq[4];  // HashEntry: code | type | card_id, level, attr_id | race_id
+    const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint32_t slot0 = (hash_code(cw[it][0]) >> 7) & a.table_mask;
+      if (!(YGO_SKIP & (32 | 64))) tq[it] = table_q[slot0];
+      if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
+        tq[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
+      if (YGO_SKIP & 32) tq[it] = make_uint4(0, 0, 0, 0);
+    }
+    uint2 ax[4];  // HashAux of the lane's overlay materials
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      ax[it] = make_uint2(0, 0);
+      if ((cw[it][2] >> 24) && !(YGO_SKIP & (32 | 64)))
+        ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[(hash_code(cw[it][0]) >> 7) & a.table_mask];
+    }
+    YGO_STAMP(0);
+
+    // ---- C: scalars + Env::Allocate common fields (env.h:196-222); previous env's images ----
     if (lane == 0) {
       const bool done = (w[1] >> 24) != 0;
       const int elapsed = (int)w[3];
@@ -349,6 +408,26 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
       a.out.to_play[e] = to_play;
       a.out.is_selfplay[e] = (int)(w[1] & 0xff);
       a.out.win_reason[e] = (int)w[7];
+    }
+    if (e_prev >= 0) flush_env(e_prev, lane);
+    e_prev = e;
+    YGO_STAMP(1);
+
+    // ---- D ----
+    wave_fence();
+    wave_zero16(lds, arena + cv.cards, cv.zero_bytes, lane);
+    wave_fence();
+
+    // ---- E: hidden opponent locations get placeholder rows {col2 = location id, col4 = 1}
+    // (:1526-1532); obs:global_ (:1605-1620) ----
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph)
+      for (int q = lane; q < ph_cnt[ph]; q += 64) {
+        uint8_t* prow = my_cards + (ph_row[ph] + q) * 39;
+        prow[2] = (uint8_t)(ph == 0 ? 1 : (ph == 1 ? 2 : 7));
+        prow[4] = 1;
+      }
+    if (lane == 0) {
       if (no_options) {
         my_global[7] = 1;  // :1839
       } else {
@@ -362,270 +441,200 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
         my_global[6] = to_play == turn_player ? 1 : 0;
       }
     }
+    // rings longer than 512 bytes: the tail goes from the stage to the image now
+    if (hist_bytes > 512 && !no_options) {
+      const int shift = ha_p * nf;
+      for (int src = 512 + lane; src < hist_bytes; src += 64) {
+        int dst = src - shift;
+        if (dst < 0) dst += hist_bytes;
+        my_hact[dst] = (stage + cv.off_hist)[src];
+      }
+    }
+    YGO_STAMP(2);
 
-    if (no_options) {
-      wave_fence();
-      if (e_next < a.n) fetch(e_next);
-    } else {
-      uint8_t* g_actions0 = a.out.actions + e * (int64_t)(a.max_options * nf);
-      uint8_t* g_hact0 = a.out.h_actions + e * (int64_t)hist_bytes;
-      uint8_t* g_hcids0 = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
-      uint8_t* my_actions = lds + arena + cv.actions + (int)((uintptr_t)g_actions0 & 15);
-      uint8_t* my_hact = lds + arena + cv.hact + (int)((uintptr_t)g_hact0 & 15);
-      uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((uintptr_t)g_hcids0 & 14));
-      // ---- the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128,
-      // l+192 and option l; the history ring is held four bytes per lane. They stay PACKED (raw
-      // dwords) until the code that needs a field: unpacked early they cost 60 more VGPRs. ----
-      uint32_t cw[4][5];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack | defense
-      uint32_t mw[11];     // ygo_option: feats[0..8], n_specs, pad | spec_key[8]
+    // ---- F: collisions (load factor <= 0.5): keep probing, rarely ----
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-#pragma unroll
-        for (int d = 0; d < 5; ++d) cw[it][d] = 0;
-        if (lane + 64 * it < n_listed) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + (lane + 64 * it) * 5;
-#pragma unroll
-          for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
+    for (int it = 0; it < 4; ++it) {
+      if (lane + 64 * it < n_listed && (tq[it].y & kEntryValid) && tq[it].x != cw[it][0]) {
+        uint32_t slot = (hash_code(cw[it][0]) >> 7) & a.table_mask;
+        uint4 found = make_uint4(0, 0, 0, 0);
+        for (uint32_t probe = 0; probe < a.table_mask; ++probe) {
+          slot = (slot + 1) & a.table_mask;
+          const uint4 cand = table_q[slot];
+          if (!(cand.y & kEntryValid)) break;
+          if (cand.x == cw[it][0]) { found = cand; break; }
         }
+        tq[it] = found;
+        if (cw[it][2] >> 24) ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[slot];
       }
+    }
 #pragma unroll
-      for (int d = 0; d < 11; ++d) mw[d] = 0;
-      if (lane < n_opt) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + lane * 11;
-#pragma unroll
-        for (int d = 0; d < 11; ++d) mw[d] = src[d];
+    for (int it = 0; it < 4; ++it)
+      if (cw[it][2] >> 24) {
+        cw[it][3] = ax[it].x;
+        cw[it][4] = ax[it].y;
       }
-      uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
-      {
-        const uint32_t* ring_w = reinterpret_cast<const uint32_t*>(stage + cv.off_hist);
-        if (4 * lane < hist_bytes) hw[0] = ring_w[lane];
-        if (256 + 4 * lane < hist_bytes) hw[1] = ring_w[64 + lane];
-      }
-      // ---- static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's
-      // cards are in flight together. An overlay material shows its static attack / defense
-      // (c_get_card copy, :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
-      uint4 tq[4];  // HashEntry: code | type | card_id, level, attr_id | race_id
-      const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
-      // (unconditional loads: a lane without a card probes the slot of code 0, in bounds, and
-      // ignores the answer - a conditional load would make the compiler wait for each in turn)
+    // every table read has returned (make the compiler settle them here: a wait for one of them
+    // after the prefetch below would also wait for the prefetch)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const uint32_t slot0 = (hash_code(cw[it][0]) >> 7) & a.table_mask;
-        if (!(YGO_SKIP & (32 | 64))) tq[it] = table_q[slot0];
-        if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
-          tq[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
-        if (YGO_SKIP & 32) tq[it] = make_uint4(0, 0, 0, 0);
-      }
-      uint2 ax[4];  // HashAux of the lane's overlay materials
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        ax[it] = make_uint2(0, 0);
-        if ((cw[it][2] >> 24) && !(YGO_SKIP & (32 | 64)))
-          ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[(hash_code(cw[it][0]) >> 7) & a.table_mask];
-      }
-      // rings longer than 512 bytes: the tail goes from the stage to the image now
-      if (hist_bytes > 512) {
-        const int shift = ha_p * nf;
-        for (int src = 512 + lane; src < hist_bytes; src += 64) {
-          int dst = src - shift;
-          if (dst < 0) dst += hist_bytes;
-          my_hact[dst] = (stage + cv.off_hist)[src];
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {  // collisions (load factor <= 0.5): keep probing, rarely
-        if (lane + 64 * it < n_listed && (tq[it].y & kEntryValid) && tq[it].x != cw[it][0]) {
-          uint32_t slot = (hash_code(cw[it][0]) >> 7) & a.table_mask;
-          uint4 found = make_uint4(0, 0, 0, 0);
-          for (uint32_t probe = 0; probe < a.table_mask; ++probe) {
-            slot = (slot + 1) & a.table_mask;
-            const uint4 cand = table_q[slot];
-            if (!(cand.y & kEntryValid)) break;
-            if (cand.x == cw[it][0]) { found = cand; break; }
-          }
-          tq[it] = found;
-          if (cw[it][2] >> 24) ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[slot];
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-        if (cw[it][2] >> 24) {
-          cw[it][3] = ax[it].x;
-          cw[it][4] = ax[it].y;
-        }
-      // every table read has returned (make the compiler settle them here: a wait for one of
-      // them after the prefetch below would also wait for the prefetch)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-        asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
-      YGO_STAMP(1);
-      // ---- the stage is consumed: the next env's record starts its way in ----
-      wave_fence();
-      if (e_next < a.n) fetch(e_next);
-      YGO_STAMP(2);
+    for (int it = 0; it < 4; ++it)
+      asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
+    YGO_STAMP(3);
 
-      // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
-      // written: the image starts zeroed. Every listed row also enters the env's direct-mapped
-      // spec table (the reference's per-step spec2index hash map, :1549). ----
+    // ---- G ----
+    wave_fence();
+    if (e + n_waves < a.n) fetch(e + n_waves);
+
+    // ---- H ----
+    // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
+    // written: the image starts zeroed. Every listed row also enters the env's direct-mapped
+    // spec table (the reference's per-step spec2index hash map, :1549). ----
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        // one card at a time, unpacked here and no earlier
-        asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
-        const int k = lane + 64 * it;
-        if (k < n_listed && !(YGO_SKIP & 1)) {
-          const uint32_t sv = segv[it];
-          const int s = (sv >> 13) & 15;
-          const int pi = s >= 7 ? 1 : 0, li = s - 7 * pi;
-          const int r = k + (int)(sv & 8191) - 4096;
-          uint32_t key = 0xffffffffu;
-          if (sv & (1u << 17)) {
-            ygo_card c;
-            c.code = cw[it][0];
-            c.controller = (uint8_t)cw[it][1]; c.location = (uint8_t)(cw[it][1] >> 8);
-            c.sequence = (uint8_t)(cw[it][1] >> 16); c.position = (uint8_t)(cw[it][1] >> 24);
-            c.level = (uint8_t)cw[it][2]; c.rank = (uint8_t)(cw[it][2] >> 8);
-            c.link = (uint8_t)(cw[it][2] >> 16); c.is_material = (uint8_t)(cw[it][2] >> 24);
-            c.attack = (int32_t)cw[it][3]; c.defense = (int32_t)cw[it][4];
-            HashEntry t;
-            t.code = tq[it].x; t.type = tq[it].y;
-            t.card_id = (uint16_t)tq[it].z; t.level = (uint8_t)(tq[it].z >> 16); t.attr_id = (uint8_t)(tq[it].z >> 24);
-            t.race_id = (uint8_t)tq[it].w;
-            const bool known = (t.type & kEntryValid) && t.code == c.code;
-            uint8_t* row = my_cards + r * 39;
-            const uint32_t loc7 = c.location & 0x7f;
-            const bool overlay = (c.location & 0x80) != 0;
-            bool hide = false;
-            if (pi == 1) {
-              hide = (c.position & 0xa) != 0;  // POS_FACEDOWN (:1540)
-              if (li == 1 && c.sequence < 64 && ((hand_mask >> c.sequence) & 1ull)) hide = false;
-            }
-            if (overlay) hide = false;  // :1562-1564
-            if (!known) { bad = true; hide = true; }
-            const uint8_t lid = loc_id(loc7);
-            if (lid == 0) bad = true;
-            row[2] = lid;
-            row[3] = (loc7 == 0x04 || loc7 == 0x08 || loc7 == 0x10) ? (uint8_t)(c.sequence + 1) : (uint8_t)0;  // :1573-1578
-            row[4] = (c.controller != to_play) ? 1 : 0;
-            const uint8_t pid = pos_id(c.position);
-            if (!overlay && pid == 0xff) bad = true;
-            row[5] = overlay ? (uint8_t)5 : (pid == 0xff ? (uint8_t)0 : pid);  // overlay: position2id.at(POS_FACEUP)
-            row[6] = overlay ? 1 : 0;
-            if (!hide) {
-              row[0] = (uint8_t)(t.card_id >> 8);
-              row[1] = (uint8_t)(t.card_id & 0xff);
-              if (t.attr_id == 0xff || t.race_id == 0xff) bad = true;
-              row[7] = t.attr_id == 0xff ? 0 : t.attr_id;
-              row[8] = t.race_id == 0xff ? 0 : t.race_id;
-              int level = t.level, atk = c.attack, def = c.defense;
-              if (!c.is_material) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
-                if (c.level > 0) level = c.level;
-                if (c.rank > 0) level = c.rank;
-                if (c.link > 0) level = c.link;
-              }
-              row[9] = (uint8_t)level;
-              ft(atk, row[10], row[11]);
-              ft(def, row[12], row[13]);
-              // type_to_ids (:635-642): one byte per TYPE_* key in ascending order; set bits only
-              uint32_t tb = t.type & 0x07ff7ff7u;
-              while (tb) {
-                const int b = __ffs(tb) - 1;
-                tb &= tb - 1;
-                row[14 + (b < 3 ? b : (b < 15 ? b - 1 : b - 2))] = 1;
-              }
-            }
-            key = (uint32_t)pi | (loc7 << 8) | ((uint32_t)c.sequence << 16) | ((overlay ? (uint32_t)c.position + 1u : 0u) << 24);
-            const int ti = spec_slot(key, a.max_cards);
-            if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
-            my_krow[k] = (uint8_t)(r + 1);  // row of listed card k
+    for (int it = 0; it < 4; ++it) {
+      // one card at a time, unpacked here and no earlier
+      asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
+      const int k = lane + 64 * it;
+      if (k < n_listed && !(YGO_SKIP & 1)) {
+        const uint32_t sv = segv[it];
+        const int s = (sv >> 13) & 15;
+        const int pi = s >= 7 ? 1 : 0, li = s - 7 * pi;
+        const int r = k + (int)(sv & 8191) - 4096;
+        uint32_t key = 0xffffffffu;
+        if (sv & (1u << 17)) {
+          ygo_card c;
+          c.code = cw[it][0];
+          c.controller = (uint8_t)cw[it][1]; c.location = (uint8_t)(cw[it][1] >> 8);
+          c.sequence = (uint8_t)(cw[it][1] >> 16); c.position = (uint8_t)(cw[it][1] >> 24);
+          c.level = (uint8_t)cw[it][2]; c.rank = (uint8_t)(cw[it][2] >> 8);
+          c.link = (uint8_t)(cw[it][2] >> 16); c.is_material = (uint8_t)(cw[it][2] >> 24);
+          c.attack = (int32_t)cw[it][3]; c.defense = (int32_t)cw[it][4];
+          HashEntry t;
+          t.code = tq[it].x; t.type = tq[it].y;
+          t.card_id = (uint16_t)tq[it].z; t.level = (uint8_t)(tq[it].z >> 16); t.attr_id = (uint8_t)(tq[it].z >> 24);
+          t.race_id = (uint8_t)tq[it].w;
+          const bool known = (t.type & kEntryValid) && t.code == c.code;
+          uint8_t* row = my_cards + r * 39;
+          const uint32_t loc7 = c.location & 0x7f;
+          const bool overlay = (c.location & 0x80) != 0;
+          bool hide = false;
+          if (pi == 1) {
+            hide = (c.position & 0xa) != 0;  // POS_FACEDOWN (:1540)
+            if (li == 1 && c.sequence < 64 && ((hand_mask >> c.sequence) & 1ull)) hide = false;
           }
-          my_rowkey[k] = key;
-        }
-      }
-      wave_fence();
-      YGO_STAMP(3);
-      // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
-      // one of them, the reference the LAST one; detect it and take the exact scan instead
-      bool dup = false;
-      for (int k = lane; k < n_listed && !(YGO_SKIP & 2); k += 64) {
-        const uint32_t key = my_rowkey[k];
-        const int ti = key == 0xffffffffu ? -1 : spec_slot(key, a.max_cards);
-        if (ti >= 0 && my_spec[ti] != my_krow[k]) dup = true;
-      }
-      dup = __any(dup);
-      // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
-      if (!(YGO_SKIP & 4)) {
-        const int shift = ha_p * nf;
-#pragma unroll
-        for (int ww = 0; ww < 2; ++ww) {
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const int src = 256 * ww + 4 * lane + bb;  // ring byte held by this lane
-            const uint8_t v = (uint8_t)(hw[ww] >> (8 * bb));
-            if (src < hist_bytes && v) {
-              int dst = src - shift;
-              if (dst < 0) dst += hist_bytes;
-              my_hact[dst] = v;
+          if (overlay) hide = false;  // :1562-1564
+          if (!known) { bad = true; hide = true; }
+          const uint8_t lid = loc_id(loc7);
+          if (lid == 0) bad = true;
+          row[2] = lid;
+          row[3] = (loc7 == 0x04 || loc7 == 0x08 || loc7 == 0x10) ? (uint8_t)(c.sequence + 1) : (uint8_t)0;  // :1573-1578
+          row[4] = (c.controller != to_play) ? 1 : 0;
+          const uint8_t pid = pos_id(c.position);
+          if (!overlay && pid == 0xff) bad = true;
+          row[5] = overlay ? (uint8_t)5 : (pid == 0xff ? (uint8_t)0 : pid);  // overlay: position2id.at(POS_FACEUP)
+          row[6] = overlay ? 1 : 0;
+          if (!hide) {
+            row[0] = (uint8_t)(t.card_id >> 8);
+            row[1] = (uint8_t)(t.card_id & 0xff);
+            if (t.attr_id == 0xff || t.race_id == 0xff) bad = true;
+            row[7] = t.attr_id == 0xff ? 0 : t.attr_id;
+            row[8] = t.race_id == 0xff ? 0 : t.race_id;
+            int level = t.level, atk = c.attack, def = c.defense;
+            if (!c.is_material) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
+              if (c.level > 0) level = c.level;
+              if (c.rank > 0) level = c.rank;
+              if (c.link > 0) level = c.link;
+            }
+            row[9] = (uint8_t)level;
+            ft(atk, row[10], row[11]);
+            ft(def, row[12], row[13]);
+            // type_to_ids (:635-642): one byte per TYPE_* key in ascending order; set bits only
+            uint32_t tb = t.type & 0x07ff7ff7u;
+            while (tb) {
+              const int b = __ffs(tb) - 1;
+              tb &= tb - 1;
+              row[14 + (b < 3 ? b : (b < 15 ? b - 1 : b - 2))] = 1;
             }
           }
+          key = (uint32_t)pi | (loc7 << 8) | ((uint32_t)c.sequence << 16) | ((overlay ? (uint32_t)c.position + 1u : 0u) << 24);
+          const int ti = spec_slot(key, a.max_cards);
+          if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
+          my_krow[k] = (uint8_t)(r + 1);  // row of listed card k
         }
+        my_rowkey[k] = key;
       }
-      YGO_STAMP(4);
-      // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
+    }
+    wave_fence();
+    YGO_STAMP(4);
+    // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
+    // one of them, the reference the LAST one; detect it and take the exact scan instead
+    bool dup = false;
+    for (int k = lane; k < n_listed && !(YGO_SKIP & 2); k += 64) {
+      const uint32_t key = my_rowkey[k];
+      const int ti = key == 0xffffffffu ? -1 : spec_slot(key, a.max_cards);
+      if (ti >= 0 && my_spec[ti] != my_krow[k]) dup = true;
+    }
+    dup = __any(dup);
+    // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
+    if (!no_options && !(YGO_SKIP & 4)) {
+      const int shift = ha_p * nf;
 #pragma unroll
-      for (int d = 0; d < 11; ++d) asm volatile("" : "+v"(mw[d]));
-      if (lane < n_opt && !(YGO_SKIP & 8)) {
-        uint8_t* arow = my_actions + lane * nf;
-        const int ns = min((int)((mw[2] >> 8) & 0xff), a.mms);
-        bool open = true;
+      for (int ww = 0; ww < 2; ++ww) {
 #pragma unroll
-        for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
-          if (j < ns) {
-            const uint32_t key = mw[3 + j];
-            const int ti = spec_slot(key, a.max_cards);
-            int idx = 0;
-            if (ti >= 0 && !dup) {
-              idx = my_spec[ti];
-            } else {
-              for (int k = 0; k < n_listed; ++k)
-                if (my_rowkey[k] == key) idx = max(idx, (int)my_krow[k]);  // last row wins (:1549)
-            }
-            if (idx == 0) bad = true;  // spec2index.at(spec) throws
-            arow[2 * j] = (uint8_t)(idx >> 8);
-            arow[2 * j + 1] = (uint8_t)(idx & 0xff);
-            // read back from the images, literally: low byte only (Q7), stop at the first zero
-            const int spec_index = idx & 0xff;
-            if (spec_index == 0) open = false;
-            if (open) {
-              const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
-              my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
-            }
+        for (int bb = 0; bb < 4; ++bb) {
+          const int src = 256 * ww + 4 * lane + bb;  // ring byte held by this lane
+          const uint8_t v = (uint8_t)(hw[ww] >> (8 * bb));
+          if (src < hist_bytes && v) {
+            int dst = src - shift;
+            if (dst < 0) dst += hist_bytes;
+            my_hact[dst] = v;
           }
         }
+      }
+    }
+    // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
-          if (f) arow[2 * a.mms + k] = f;
+    for (int d = 0; d < 11; ++d) asm volatile("" : "+v"(mw[d]));
+    if (lane < n_opt && !(YGO_SKIP & 8)) {
+      uint8_t* arow = my_actions + lane * nf;
+      const int ns = min((int)((mw[2] >> 8) & 0xff), a.mms);
+      bool open = true;
+#pragma unroll
+      for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
+        if (j < ns) {
+          const uint32_t key = mw[3 + j];
+          const int ti = spec_slot(key, a.max_cards);
+          int idx = 0;
+          if (ti >= 0 && !dup) {
+            idx = my_spec[ti];
+          } else {
+            for (int k = 0; k < n_listed; ++k)
+              if (my_rowkey[k] == key) idx = max(idx, (int)my_krow[k]);  // last row wins (:1549)
+          }
+          if (idx == 0) bad = true;  // spec2index.at(spec) throws
+          arow[2 * j] = (uint8_t)(idx >> 8);
+          arow[2 * j + 1] = (uint8_t)(idx & 0xff);
+          // read back from the images, literally: low byte only (Q7), stop at the first zero
+          const int spec_index = idx & 0xff;
+          if (spec_index == 0) open = false;
+          if (open) {
+            const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
+            my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
+          }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
+        if (f) arow[2 * a.mms + k] = f;
       }
     }
     YGO_STAMP(5);
     if (__any(bad) && lane == 0) *a.err = 1u;
     wave_fence();
-
-    // ---- the env's images leave the CU: aligned 16-byte-per-lane stores for the bulk ----
-    {
-      uint8_t* g_actions = a.out.actions + e * (int64_t)(a.max_options * nf);
-      uint8_t* g_hact = a.out.h_actions + e * (int64_t)hist_bytes;
-      uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
-      if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, img_lo, R * 39, lane);
-      wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
-      wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
-      wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
-      if (lane < 8) a.out.global[e * 8 + lane] = my_global[lane];
-    }
-    wave_fence();  // the images are read out before the next env zeroes them
-    YGO_STAMP(6);
   }
+  vm_wait<0>();
+  flush_env(e_prev, lane0);
+  YGO_STAMP_END(6);
 }
 
 }  // namespace ygk
