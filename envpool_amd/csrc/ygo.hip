@@ -79,7 +79,6 @@ struct ep_ygo_encoder {
   size_t out_bytes = 0;
   uint64_t submit_idx = 0, collect_idx = 0;
   int lds_bytes = 0;
-  int max_groups = 1;  // resident workgroups of the whole device
   std::mutex mu;
   std::shared_ptr<epc::HostBlocks> blocks;
   bool timing = false;
@@ -134,8 +133,7 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
     HIP_TRY(hipEventCreate(&t1));
     HIP_TRY(hipEventRecord(t0, e->stream));
   }
-  // persistent waves: no more workgroups than the chip holds at once; each wave walks its envs
-  const int groups = std::min((n + ygk::kGroup - 1) / ygk::kGroup, e->max_groups);
+  const int groups = (n + ygk::kGroup - 1) / ygk::kGroup;
   hipLaunchKernelGGL(ygk::ygo_encode, dim3(groups), dim3(ygk::kThreads), e->lds_bytes, e->stream, a);
   HIP_TRY(hipGetLastError());
   if (e->timing) {
@@ -219,16 +217,6 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   if (e->lds_bytes > 160 * 1024) return fail(EP_ERR_TOO_LARGE, "config needs %d bytes of LDS per workgroup (max 163840)", e->lds_bytes);
   if (cv.off_hist != e->lay.off_hist || cv.off_cards != e->lay.off_cards || cv.off_opts != e->lay.off_opts || cv.rec_bytes > e->lay.stride)
     return fail(EP_ERR_INVALID, "internal: kernel and host record layouts disagree");
-  {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
-    // 3 waves per SIMD (the kernel's launch bounds) = 12 per CU, or what the LDS arenas allow
-    const int by_lds = (160 * 1024) / e->lds_bytes;
-    const int by_waves = std::max(1, 12 / ygk::kGroup);
-    e->max_groups = std::max(1, prop.multiProcessorCount * std::min(by_lds, by_waves));
-  }
-  if (e->lds_bytes > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)ygk::ygo_encode, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   // output block layout
   const size_t B = (size_t)cfg->max_batch;
   const int nf = e->lay.nf;

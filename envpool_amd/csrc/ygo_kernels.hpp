@@ -23,7 +23,7 @@
 namespace ygk {
 
 #ifndef YGO_WAVES
-#define YGO_WAVES 4
+#define YGO_WAVES 2
 #endif
 constexpr int kGroup = YGO_WAVES;       // envs (= waves) per workgroup; any value works
 constexpr int kThreads = 64 * kGroup;   // one wave64 per env
@@ -71,7 +71,7 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.rec_bytes = al16(c.off_opts + max_options * (int)sizeof(ygo_option));
   c.stage_bytes = (c.rec_bytes + 1023) & ~1023;
   int o = 0;
-  c.cards = o;   o += al16(R * 39) + 16;
+  c.cards = o;   o += max(al16(R * 39) + 16, c.stage_bytes);  // doubles as the record's landing area
   c.actions = o; o += al16(max_options * nf) + 16;
   c.hact = o;    o += al16(n_hist * nf) + 16;
   c.hcids = o;   o += al16(max_options * mms * 2) + 16;
@@ -81,7 +81,7 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.zero_bytes = o;
   c.rowkey_stride = al16(R * 4 + R);  // key of listed card k (u32), then its row (u8)
   c.rowkey = o;  o += c.rowkey_stride;
-  c.stage = o;   o += c.stage_bytes;  // the NEXT env's record lands here by LDS-DMA
+  c.stage = c.cards;  // the record lands (LDS-DMA) where the card image is built afterwards
   c.wave_stride = o;
   c.total = o * kGroup;
   return c;
@@ -206,20 +206,17 @@ __device__ __forceinline__ uint32_t lane_word(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
 
-__global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
+__global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const Carve& cv = a.cv;
-  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler knows it
 #ifdef YGO_STAMPS
   unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
   const int R = 2 * a.max_cards, nf = a.nf;
   const int hist_bytes = a.n_hist * nf;
-  // persistent waves: wave g encodes envs g, g + W, g + 2W, ... one after the other, and the
-  // record of its next env travels HBM -> LDS (LDS-DMA) underneath the encode of the current one
-  const int64_t n_waves = (int64_t)gridDim.x * kGroup;
-  int64_t e = (int64_t)blockIdx.x * kGroup + wave;
+  const int64_t e = (int64_t)blockIdx.x * kGroup + wave;
   if (e >= a.n) return;  // wave-uniform; no workgroup barrier anywhere in this kernel
 
   const int arena = wave * cv.wave_stride;
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     const uint8_t* g = a.records + env * a.stride;
     lds_drain();  // every earlier LDS read of the stage has returned
     for (int c = 0; c < n_dma; ++c) {
-      const int chunk = min(lane0 + 64 * c, n_chunks - 1);  // the pad lanes re-read the last chunk
+      const int chunk = min(lane + 64 * c, n_chunks - 1);  // the pad lanes re-read the last chunk
       dma16(g + (int64_t)chunk * 16, stage_lds + 1024u * (uint32_t)c);
     }
   };
@@ -253,22 +250,17 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     if (lane < 8) a.out.global[env * 8 + lane] = my_global[lane];
   };
 
-  // Per env, in this order (VMEM retires in issue order, and the compiler cannot see the DMA, so
-  // the order is what keeps every wait short):
-  //   A  wait for this env's record (its DMA was issued a whole env ago; nothing younger is pending)
+  // Per env, in this order:
+  //   A  the record travels HBM -> LDS by LDS-DMA (no VGPR round trip) into the region where the
+  //      card image is built later; meanwhile the small images and the spec table are zeroed
+  //      (the reference's fresh zero-filled StateBuffer, array.h:77-81)
   //   B  header -> scalars, packed card / option / history words -> lanes, hash probes issued
-  //   C  scalar outputs of this env; the PREVIOUS env's images leave the CU
-  //   D  images zeroed (the reference's fresh zero-filled StateBuffer, array.h:77-81)
+  //   C  scalar outputs
+  //   D  the landing area becomes the zeroed card image
   //   E  placeholder rows, obs:global_
-  //   F  probes settled                       (waits for C's stores too, after D and E)
-  //   G  the next env's record starts its way in (the stage was consumed in B)
-  //   H  rows, options, history: LDS only, a whole phase for the DMA to land
-  int64_t e_prev = -1;
-  for (; e < a.n; e += n_waves) {
-    // the lane id is made opaque per iteration: otherwise every lane-dependent address and
-    // predicate of the body is hoisted out of the loop and held in VGPRs (240 of them)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
+  //   F  probes settled
+  //   H  rows, options, history (LDS only), then the images leave the CU
+  {
     bool bad = false;
     uint8_t* g_cards = a.out.cards + e * (int64_t)(R * 39);
     uint8_t* my_cards = lds + arena + cv.cards + (int)((uintptr_t)g_cards & 15);
@@ -279,6 +271,7 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     uint8_t* my_hact = lds + arena + cv.hact + (int)((uintptr_t)g_hact0 & 15);
     uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((uintptr_t)g_hcids0 & 14));
 
+    wave_zero16(lds, arena + cv.actions, cv.zero_bytes - cv.actions, lane);
     // ---- A ----
     vm_wait<0>();
     wave_fence();
@@ -390,9 +383,18 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
       if ((cw[it][2] >> 24) && !(YGO_SKIP & (32 | 64)))
         ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[(hash_code(cw[it][0]) >> 7) & a.table_mask];
     }
+    // rings longer than 512 bytes: the tail goes from the stage to the image now
+    if (hist_bytes > 512 && !no_options) {
+      const int shift = ha_p * nf;
+      for (int src = 512 + lane; src < hist_bytes; src += 64) {
+        int dst = src - shift;
+        if (dst < 0) dst += hist_bytes;
+        my_hact[dst] = (stage + cv.off_hist)[src];
+      }
+    }
     YGO_STAMP(0);
 
-    // ---- C: scalars + Env::Allocate common fields (env.h:196-222); previous env's images ----
+    // ---- C: scalars + Env::Allocate common fields (env.h:196-222) ----
     if (lane == 0) {
       const bool done = (w[1] >> 24) != 0;
       const int elapsed = (int)w[3];
@@ -409,13 +411,11 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
       a.out.is_selfplay[e] = (int)(w[1] & 0xff);
       a.out.win_reason[e] = (int)w[7];
     }
-    if (e_prev >= 0) flush_env(e_prev, lane);
-    e_prev = e;
     YGO_STAMP(1);
 
     // ---- D ----
     wave_fence();
-    wave_zero16(lds, arena + cv.cards, cv.zero_bytes, lane);
+    wave_zero16(lds, arena + cv.cards, cv.actions, lane);
     wave_fence();
 
     // ---- E: hidden opponent locations get placeholder rows {col2 = location id, col4 = 1}
@@ -439,15 +439,6 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
         else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
         my_global[5] = to_play == 0 ? 1 : 0;
         my_global[6] = to_play == turn_player ? 1 : 0;
-      }
-    }
-    // rings longer than 512 bytes: the tail goes from the stage to the image now
-    if (hist_bytes > 512 && !no_options) {
-      const int shift = ha_p * nf;
-      for (int src = 512 + lane; src < hist_bytes; src += 64) {
-        int dst = src - shift;
-        if (dst < 0) dst += hist_bytes;
-        my_hact[dst] = (stage + cv.off_hist)[src];
       }
     }
     YGO_STAMP(2);
@@ -480,10 +471,6 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     for (int it = 0; it < 4; ++it)
       asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
     YGO_STAMP(3);
-
-    // ---- G ----
-    wave_fence();
-    if (e + n_waves < a.n) fetch(e + n_waves);
 
     // ---- H ----
     // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
@@ -631,10 +618,9 @@ __global__ __launch_bounds__(kThreads, 3) void ygo_encode(Args a) {
     YGO_STAMP(5);
     if (__any(bad) && lane == 0) *a.err = 1u;
     wave_fence();
+    flush_env(e, lane);
+    YGO_STAMP(6);
   }
-  vm_wait<0>();
-  flush_env(e_prev, lane0);
-  YGO_STAMP_END(6);
 }
 
 }  // namespace ygk
