@@ -46,6 +46,7 @@ def main():
   ap.add_argument("--steps", type=int, default=2048)
   ap.add_argument("--warmup", type=int, default=256)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-ygo", action="store_true", help="skip the YGOPro observation-encode section")
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +131,7 @@ def main():
 
   if W:
     run_fused(W)
-  check(L.ep_pool_set_timing(h, 0 if os.environ.get("EP_BENCH_NO_EVENTS") else 1))
+  check(L.ep_pool_set_timing(h, 1))
   tot = C.c_double()
   cnt = C.c_int64()
   check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
@@ -195,6 +196,39 @@ def main():
                 "O(N^2) bytes per step there and cannot run this N at all)",
     }
 
+  # second path of the north star: the YGOPro observation-encode tail (BASELINE.json configs[2]
+  # shape: 1024 records per step through the pinned pipeline; plus a 65536-record device-resident
+  # batch for the encode kernel's own roofline figure). Reported next to the headline value.
+  ygo = None
+  if rank == 0 and world == 1 and not args.no_ygo:
+    try:
+      from tools import bench_ygo
+      r = bench_ygo.run(cpu_seconds=0.0 if args.no_cpu_baseline else 5.0)
+      big, c3 = r["large_batch"], r["config3_host_pipeline"]
+      ygo = {
+        "metric": "ygopro obs-encodes/s", "unit": "encodes/s",
+        "value_device_resident": big["encodes_per_s_wall"],
+        "value_config3_host_records_pcie_inclusive": c3["encodes_per_s_wall_pcie_inclusive"],
+        "config": {"workload": "YGOPro-v0 observation-encode tail, default config (max_cards 75, max_options 16, "
+                               "16 history actions), synthetic duel states; 65536 records per launch device-resident, "
+                               "and 1024 host records per step through the pinned submit/collect pipeline"},
+        "roofline": {"bound": "hbm", "achieved": big["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": big["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None, "kernel": "ygo_encode",
+                     "kernel_us": big["kernel_us"], "alg_bytes_per_record": big["alg_bytes_per_record"]},
+        "config3_us_per_step": c3["us_per_step_wall"], "config3_kernel_us": c3["kernel_us"],
+        "host_emit_records_per_s_1core": r["host_emit_records_per_s_1core"],
+      }
+      if "cpu_oracle_encodes_per_s_1core" in r:
+        ygo["cpu_baseline"] = {"value": r["cpu_oracle_encodes_per_s_1core"], "unit": "encodes/s", "cores": 1, "kind": "port",
+                               "sample": "about 5 s of oracle/ygo_oracle.c WriteState restatement on the same synthetic states"}
+      pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+      if os.path.exists(pmc_path):
+        t = json.load(open(pmc_path)).get("ygo_hbm_bytes_per_record")
+        if t:
+          ygo["roofline"]["traffic"] = t * big["records_per_launch"]
+    except Exception as ex:  # the headline line must still be printed
+      ygo = {"error": repr(ex)}
+
   if rank == 0:
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -227,6 +261,8 @@ def main():
     }
     if cpu is not None:
       line["cpu_baseline"] = cpu
+    if ygo is not None:
+      line["ygo_encode"] = ygo
     print(json.dumps(line), flush=True)
 
   pool.close()

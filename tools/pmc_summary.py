@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output for one kernel-name substring.
 
-usage: pmc_summary.py <dir> <kernel-substring>
+usage: pmc_summary.py <dir> <kernel-substring> [min-grid-size]
 Prints JSON: average duration (kernel trace) and per-dispatch average of every PMC counter
 found under <dir> (recursively) for dispatches whose kernel name contains the substring.
 """
@@ -14,7 +14,12 @@ import sys
 
 def main():
   root, needle = sys.argv[1], sys.argv[2]
-  out = {"kernel": needle}
+  min_grid = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+  out = {"kernel": needle, "min_grid": min_grid}
+
+  def keep(r):
+    return needle in r.get("Kernel_Name", "") and int(r.get("Grid_Size", min_grid) or 0) >= min_grid
+
   for path in sorted(glob.glob(os.path.join(root, "**", "*.csv"), recursive=True)):
     with open(path, newline="") as f:
       rows = list(csv.DictReader(f))
@@ -22,14 +27,14 @@ def main():
       continue
     cols = rows[0].keys()
     if "Start_Timestamp" in cols and "Kernel_Name" in cols and "Counter_Name" not in cols:
-      d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if needle in r["Kernel_Name"]]
+      d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if keep(r)]
       if d:
         out.setdefault("trace", {})[os.path.relpath(path, root)] = {
           "calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
     if "Counter_Name" in cols and "Counter_Value" in cols:
       acc = {}
       for r in rows:
-        if needle in r.get("Kernel_Name", ""):
+        if keep(r):
           acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
       for k, v in acc.items():
         out.setdefault("pmc", {})[k] = {"dispatches": len(v), "avg": sum(v) / len(v)}
