@@ -177,6 +177,29 @@ def main():
       "note": "ep_pool_send + blocking ep_pool_recv per lockstep step, device-resident actions",
     }
 
+  # the boundary also takes host buffers (the reference's numpy path): PCIe-inclusive rate,
+  # host actions in, host StateBuffer out, one launch per step. Reported, never `value`.
+  if rank == 0 and world == 1:
+    import numpy as np
+    hk = 64
+    h_env = np.arange(N, dtype=np.int32)
+    h_la = np.full((N, 6), 1.5, dtype=np.float64)
+    h_z = np.zeros(N, dtype=np.int32)
+    ph = (C.c_void_p * 5)(h_env.ctypes.data, h_env.ctypes.data, h_la.ctypes.data, h_z.ctypes.data, h_z.ctypes.data)
+    for _ in range(4):
+      check(L.ep_pool_send(h, 5, ph, dims, capi.EP_MEM_HOST))
+      check(L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)))
+      L.ep_batch_release(C.byref(batch))
+    s0 = time.perf_counter()
+    for _ in range(hk):
+      check(L.ep_pool_send(h, 5, ph, dims, capi.EP_MEM_HOST))
+      check(L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)))
+      L.ep_batch_release(C.byref(batch))
+    s1 = time.perf_counter()
+    per_step["host_buffers_pcie_inclusive"] = {
+      "value": N * hk / (s1 - s0), "unit": "env-steps/s", "ms_per_step": (s1 - s0) / hk * 1e3,
+      "note": "numpy actions in (4 MiB/step), numpy StateBuffer out (4.4 MiB/step), pageable host memory"}
+
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     from oracle.dummy_oracle import DummyOracle
