@@ -337,3 +337,44 @@ uint64_t od_bench_sync(od_pool* p, int32_t steps) {
   free(la);
   return sum;
 }
+
+/* ---- multi-threaded CPU baseline (bench.py cpu_baseline only) -----------------------------
+ * The reference runs its envs on a thread pool (async_envpool.h:105-135). The port's
+ * counterpart: `threads` independent shards of the same pool, one per core, each the sequential
+ * program above over a contiguous env_id block (seed_ uses the global id, so the union is the
+ * one big pool). No lockstep barrier between shards: this favours the CPU. */
+#include <pthread.h>
+
+typedef struct {
+  int32_t n, off, seed, steps;
+  uint64_t sum;
+} od_mt_arg;
+
+static void* od_mt_run(void* v) {
+  od_mt_arg* a = (od_mt_arg*)v;
+  od_pool* p = od_create(a->n, a->n, 1, a->seed, 2147483647, 10, a->off);
+  a->sum = p ? od_bench_sync(p, a->steps) : 0;
+  od_destroy(p);
+  return NULL;
+}
+
+uint64_t od_bench_sync_mt(int32_t num_envs, int32_t seed, int32_t steps, int32_t threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t th[256];
+  od_mt_arg arg[256];
+  int32_t per = (num_envs + threads - 1) / threads, started = 0;
+  for (int t = 0; t < threads; ++t) {
+    int32_t off = t * per, n = num_envs - off < per ? num_envs - off : per;
+    if (n <= 0) break;
+    arg[t] = (od_mt_arg){n, off, seed, steps, 0};
+    if (pthread_create(&th[t], NULL, od_mt_run, &arg[t]) != 0) break;
+    ++started;
+  }
+  uint64_t sum = 0;
+  for (int t = 0; t < started; ++t) {
+    pthread_join(th[t], NULL);
+    sum += arg[t].sum;
+  }
+  return sum;
+}

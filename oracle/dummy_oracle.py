@@ -48,6 +48,8 @@ def lib():
     L.od_batch_free.argtypes = [C.POINTER(_Batch)]
     L.od_bench_sync.restype = C.c_uint64
     L.od_bench_sync.argtypes = [C.c_void_p, C.c_int32]
+    L.od_bench_sync_mt.restype = C.c_uint64
+    L.od_bench_sync_mt.argtypes = [C.c_int32] * 4
     L.od_queue_size.argtypes = [C.c_void_p]
     L.od_is_sync.argtypes = [C.c_void_p]
     _LIB = L
@@ -133,3 +135,8 @@ class DummyOracle:
 
   def bench_sync(self, steps):
     return self._L.od_bench_sync(self._p, steps)
+
+
+def bench_sync_mt(num_envs, seed, steps, threads):
+  """bench.py's multi-threaded cpu_baseline leg: `threads` independent shards of one sync pool."""
+  return lib().od_bench_sync_mt(num_envs, seed, steps, threads)
