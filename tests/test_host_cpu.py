@@ -228,3 +228,29 @@ def test_sharded_stats_all_gather_gloo_world2(tmp_path):
      "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=240)
   assert out.returncode == 0, out.stdout + out.stderr
   assert out.stdout.count("ok") == 2
+
+
+def test_ygopro_spec_surface():
+  """ygopro.h:1177-1207 + env_spec.h:25-42: keys, defaults, dtypes, shapes, bounds."""
+  import envpool_amd
+  from envpool_amd.ygopro import YGOProEnvSpec, _YGOProEnvSpec
+  assert "YGOPro-v0" in envpool_amd.list_all_envs()
+  assert _YGOProEnvSpec._config_keys[9:] == ["deck1", "deck2", "player", "play_mode", "verbose", "max_options",
+                                              "max_cards", "n_history_actions", "max_multi_select"]
+  assert _YGOProEnvSpec._default_config_values[9:] == ("OldSchool", "OldSchool", -1, "bot", False, 16, 75, 16, 5)
+  spec = envpool_amd.make_spec("YGOPro-v0", num_envs=1024)
+  assert isinstance(spec, YGOProEnvSpec) and spec.config.batch_size == 1024 and spec.config.max_cards == 75
+  st = spec.state_array_spec
+  assert list(st)[:8] == GOLD["state_keys"][:8]
+  u8 = np.dtype(np.uint8)
+  assert (st["obs:cards_"].dtype, st["obs:cards_"].shape) == (u8, [150, 39])
+  assert st["obs:global_"].shape == [8] and st["obs:actions_"].shape == [16, 19] and st["obs:h_actions_"].shape == [16, 19]
+  assert (st["info:num_options"].minimum, st["info:num_options"].maximum) == (0, 15)
+  assert (st["info:win_reason"].minimum, st["info:win_reason"].maximum) == (-1, 1)
+  ac = spec.action_array_spec
+  assert list(ac) == ["env_id", "players.env_id", "action"] and (ac["action"].minimum, ac["action"].maximum) == (0, 15)
+  s2 = envpool_amd.make_spec("YGOPro-v0", num_envs=8, max_multi_select=4, max_cards=60, n_history_actions=8)
+  assert s2.state_array_spec["obs:actions_"].shape == [16, 17] and s2.state_array_spec["obs:cards_"].shape == [120, 39]
+  assert s2.state_array_spec["obs:h_actions_"].shape == [8, 17]
+  with pytest.raises(RuntimeError, match="duel engine"):
+    envpool_amd.make("YGOPro-v0", "raw", num_envs=2)

@@ -44,6 +44,7 @@ def test_known_answers_on_gpu():
 
 @pytest.mark.parametrize("n,seed,kw", [
   (1, 1, {}), (7, 2, {}), (8, 3, {}), (1000, 4, {}), (20000, 5, {}),
+  (20000, 15, {}), (20000, 25, {}), (20000, 35, {}), (20000, 45, {}),  # 10^5 randomised records in all
   (513, 6, dict(max_cards=60, max_options=12, n_history_actions=8, max_multi_select=3)),
   (300, 7, dict(max_cards=100, max_options=24, n_history_actions=20, max_multi_select=8)),
 ])
@@ -129,3 +130,33 @@ def test_submit_collect_pipeline_and_device_records():
   got = capi.batch_to_numpy(bt)
   L.ep_batch_release(C.byref(bt))
   _compare(got, want, ok, "device records")
+
+
+def test_python_front_end_and_action_mask():
+  """envpool_amd.ygopro.YGOProEncoder: dict in `_state_keys` order + the implicit legal-action mask
+  (rows >= num_options of obs:actions_ stay zero)."""
+  import envpool_amd
+  from envpool_amd.ygopro import YGOProEncoder
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  n = 256
+  spec = envpool_amd.make_spec("YGOPro-v0", num_envs=n)
+  table = ygo_synth.make_table(1000, seed=3)
+  rows = [(t.code, t.type, t.level, t.attribute, t.race, t.attack, t.defense, t.card_id) for t in table]
+  enc = YGOProEncoder(spec, rows)
+  sb = ygo_synth.SynthBatch(enc.cfg, table, n, seed=3)
+  want, status = ygo_oracle.write_batch(enc.cfg, table, sb.raw, n)
+  recs, est = capi_ygo.emit_records(enc.cfg, sb.raw, n)
+  out = enc.encode(recs, strict=False)
+  keys = list(out)
+  assert keys[:16] == list(spec._state_keys) and keys[16:] == ["aux:h_card_ids", "mask"]
+  ok = np.nonzero((status == 0) & (est == 0))[0]
+  _compare([out[k] for k in capi_ygo.YGO_STATE_KEYS], want, ok, "front end")
+  acts = out["obs:actions_"][ok]
+  nopt = out["info:num_options"][ok]
+  mask = out["mask"][ok]
+  assert mask.shape == (len(ok), 16) and (mask.sum(1) == np.minimum(nopt, 16)).all()
+  assert (acts[~mask] == 0).all()  # rows past num_options are all zero
+  has_opts = out["obs:global_"][ok][:, 7] == 0
+  assert (acts[has_opts][:, 0, 10] != 0).all()  # a real option always carries its msg id (col 2*mms)
+  enc.close()
