@@ -302,7 +302,9 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
     ygk::HashEntry h;
     memset(&h, 0, sizeof(h));
     h.code = c.code;
-    h.type = c.type | ygk::kEntryValid;  // TYPE_* uses bits 0..26
+    h.type = ygk::kEntryValid;
+    for (int j = 0; j < 25; ++j)  // type_to_ids order (ygopro.h:635-642)
+      if (c.type & ygk::type_bit(j)) h.type |= 1u << j;
     h.card_id = c.card_id;
     h.level = (uint8_t)c.level;
     // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7

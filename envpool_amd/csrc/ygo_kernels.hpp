@@ -30,7 +30,7 @@ constexpr int kThreads = 64 * kGroup;   // one wave64 per env
 
 struct __align__(16) HashEntry {  // 16 bytes: one 16-byte load per probe
   uint32_t code;
-  uint32_t type;     // TYPE_* bits (27 used); bit 31 = entry valid
+  uint32_t type;     // TYPE_* flags compacted to bits 0..24 in ascending key order (:607-633); bit 31 = entry valid
   uint16_t card_id;
   uint8_t level;
   uint8_t attr_id;   // attribute2id value, 0xff if the reference's .at() would throw
@@ -118,7 +118,7 @@ __device__ __forceinline__ uint8_t pos_id(uint32_t p) {
     case 0x5: return 5; case 0x8: return 6; case 0xa: return 7; case 0xc: return 8; default: return 0xff;
   }
 }
-__device__ __forceinline__ uint32_t type_bit(int j) {  // ascending TYPE_* keys (:607-633)
+__host__ __device__ inline uint32_t type_bit(int j) {  // ascending TYPE_* keys (:607-633)
   // 0x1,0x2,0x4, 0x10..0x4000 (bits 4..14), 0x10000..0x4000000 (bits 16..26)
   return j < 3 ? (1u << j) : (j < 14 ? (1u << (j + 1)) : (1u << (j + 2)));
 }
@@ -473,79 +473,81 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     YGO_STAMP(3);
 
     // ---- H ----
-    // ---- obs:cards_ : one lane per LISTED card (:1508-1603). Only non-zero bytes are
-    // written: the image starts zeroed. Every listed row also enters the env's direct-mapped
-    // spec table (the reference's per-step spec2index hash map, :1549). ----
+    // ---- obs:cards_ : one lane per LISTED card (:1508-1603), written branch-free: the 14 leading
+    // bytes of a row are computed with selects (hidden fields as zeros, which is what the zeroed
+    // image holds anyway) and leave as three dwords and a short; only the type flags loop.
+    // Every listed row also enters the env's direct-mapped spec table (the reference's per-step
+    // spec2index hash map, :1549). ----
+    int ti_of[4];
+    uint32_t row1_of[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       // one card at a time, unpacked here and no earlier
       asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
       const int k = lane + 64 * it;
+      ti_of[it] = -1;
+      row1_of[it] = 0;
       if (k < n_listed && !(YGO_SKIP & 1)) {
         const uint32_t sv = segv[it];
-        const int s = (sv >> 13) & 15;
-        const int pi = s >= 7 ? 1 : 0, li = s - 7 * pi;
-        const int r = k + (int)(sv & 8191) - 4096;
         uint32_t key = 0xffffffffu;
         if (sv & (1u << 17)) {
-          ygo_card c;
-          c.code = cw[it][0];
-          c.controller = (uint8_t)cw[it][1]; c.location = (uint8_t)(cw[it][1] >> 8);
-          c.sequence = (uint8_t)(cw[it][1] >> 16); c.position = (uint8_t)(cw[it][1] >> 24);
-          c.level = (uint8_t)cw[it][2]; c.rank = (uint8_t)(cw[it][2] >> 8);
-          c.link = (uint8_t)(cw[it][2] >> 16); c.is_material = (uint8_t)(cw[it][2] >> 24);
-          c.attack = (int32_t)cw[it][3]; c.defense = (int32_t)cw[it][4];
-          HashEntry t;
-          t.code = tq[it].x; t.type = tq[it].y;
-          t.card_id = (uint16_t)tq[it].z; t.level = (uint8_t)(tq[it].z >> 16); t.attr_id = (uint8_t)(tq[it].z >> 24);
-          t.race_id = (uint8_t)tq[it].w;
-          const bool known = (t.type & kEntryValid) && t.code == c.code;
+          const uint32_t c1 = cw[it][1], c2 = cw[it][2];
+          const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
+          const uint32_t seg = (sv >> 13) & 15, pi = seg >= 7 ? 1u : 0u, li = seg - 7 * pi;
+          int r = k + (int)(sv & 8191) - 4096;
+          asm volatile("" : "+v"(r));  // keep the bias out of the byte offsets below
+          const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
+          const uint32_t lid = (loc7 != 0 && (loc7 & (loc7 - 1)) == 0 && loc7 <= 0x40) ? (uint32_t)__ffs(loc7) : 0u;  // location2id
+          // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
+          const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * pos)) & 0xf : 0xfu;
+          const bool known = (tq[it].y & kEntryValid) && tq[it].x == cw[it][0];
+          bool hide = pi != 0 && (pos & 0xa) != 0 &&                                   // POS_FACEDOWN (:1540)
+                      !(li == 1 && seq < 64 && ((hand_mask >> seq) & 1ull));           // revealed (:1541-1545)
+          hide = (hide && !overlay) || !known;                                         // :1562-1564
+          const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
+          if (!known || lid == 0 || (!overlay && pid == 0xf) || (!hide && (attr == 0xff || race == 0xff))) bad = true;
+          uint32_t level = tlevel;
+          if ((c2 >> 24) == 0) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
+            if (c2 & 0xff) level = c2 & 0xff;
+            if ((c2 >> 8) & 0xff) level = (c2 >> 8) & 0xff;
+            if ((c2 >> 16) & 0xff) level = (c2 >> 16) & 0xff;
+          }
+          // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
+          const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][4] & 0xffff;
+          const uint32_t show = hide ? 0u : 0xffffffffu;
+          const uint32_t b3 = (loc7 == 0x04 || loc7 == 0x08 || loc7 == 0x10) ? seq + 1 : 0u;  // :1573-1578
+          const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
+          const uint32_t w0 = (((cid >> 8) | ((cid & 0xff) << 8)) & show) | (lid << 16) | ((b3 & 0xff) << 24);
+          const uint32_t w1 = (ctrl != (uint32_t)to_play ? 1u : 0u) | (b5 << 8) | (overlay << 16) | (((attr == 0xff ? 0u : attr) << 24) & show);
+          const uint32_t w2 = ((race == 0xff ? 0u : race) | (level << 8) | ((atk >> 8) << 16) | ((atk & 0xff) << 24)) & show;
+          const uint16_t w3 = (uint16_t)(((def >> 8) | ((def & 0xff) << 8)) & show);
           uint8_t* row = my_cards + r * 39;
-          const uint32_t loc7 = c.location & 0x7f;
-          const bool overlay = (c.location & 0x80) != 0;
-          bool hide = false;
-          if (pi == 1) {
-            hide = (c.position & 0xa) != 0;  // POS_FACEDOWN (:1540)
-            if (li == 1 && c.sequence < 64 && ((hand_mask >> c.sequence) & 1ull)) hide = false;
+          __builtin_memcpy(row, &w0, 4);
+          __builtin_memcpy(row + 4, &w1, 4);
+          __builtin_memcpy(row + 8, &w2, 4);
+          __builtin_memcpy(row + 12, &w3, 2);
+          // type_to_ids (:635-642): one byte per TYPE_* key in ascending order (the table holds the
+          // flags already compacted to bits 0..24); set bits only
+          uint32_t tb = tq[it].y & 0x01ffffffu & show;
+          while (tb) {
+            const int b = __ffs(tb) - 1;
+            tb &= tb - 1;
+            row[14 + b] = 1;
           }
-          if (overlay) hide = false;  // :1562-1564
-          if (!known) { bad = true; hide = true; }
-          const uint8_t lid = loc_id(loc7);
-          if (lid == 0) bad = true;
-          row[2] = lid;
-          row[3] = (loc7 == 0x04 || loc7 == 0x08 || loc7 == 0x10) ? (uint8_t)(c.sequence + 1) : (uint8_t)0;  // :1573-1578
-          row[4] = (c.controller != to_play) ? 1 : 0;
-          const uint8_t pid = pos_id(c.position);
-          if (!overlay && pid == 0xff) bad = true;
-          row[5] = overlay ? (uint8_t)5 : (pid == 0xff ? (uint8_t)0 : pid);  // overlay: position2id.at(POS_FACEUP)
-          row[6] = overlay ? 1 : 0;
-          if (!hide) {
-            row[0] = (uint8_t)(t.card_id >> 8);
-            row[1] = (uint8_t)(t.card_id & 0xff);
-            if (t.attr_id == 0xff || t.race_id == 0xff) bad = true;
-            row[7] = t.attr_id == 0xff ? 0 : t.attr_id;
-            row[8] = t.race_id == 0xff ? 0 : t.race_id;
-            int level = t.level, atk = c.attack, def = c.defense;
-            if (!c.is_material) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
-              if (c.level > 0) level = c.level;
-              if (c.rank > 0) level = c.rank;
-              if (c.link > 0) level = c.link;
-            }
-            row[9] = (uint8_t)level;
-            ft(atk, row[10], row[11]);
-            ft(def, row[12], row[13]);
-            // type_to_ids (:635-642): one byte per TYPE_* key in ascending order; set bits only
-            uint32_t tb = t.type & 0x07ff7ff7u;
-            while (tb) {
-              const int b = __ffs(tb) - 1;
-              tb &= tb - 1;
-              row[14 + (b < 3 ? b : (b < 15 ? b - 1 : b - 2))] = 1;
+          const uint32_t suf = overlay ? (pos + 1) & 0xff : 0u;
+          key = pi | (loc7 << 8) | (seq << 16) | (suf << 24);
+          int ti = -1;
+          if (lid != 0) {
+            if (suf == 0) {
+              if (seq < (uint32_t)a.max_cards) ti = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
+            } else if (loc7 == 0x04 && seq < 8 && suf <= 8) {
+              ti = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
             }
           }
-          key = (uint32_t)pi | (loc7 << 8) | ((uint32_t)c.sequence << 16) | ((overlay ? (uint32_t)c.position + 1u : 0u) << 24);
-          const int ti = spec_slot(key, a.max_cards);
           if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
           my_krow[k] = (uint8_t)(r + 1);  // row of listed card k
+          ti_of[it] = ti;
+          row1_of[it] = (uint32_t)(r + 1) & 0xff;
         }
         my_rowkey[k] = key;
       }
@@ -555,11 +557,9 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
     // one of them, the reference the LAST one; detect it and take the exact scan instead
     bool dup = false;
-    for (int k = lane; k < n_listed && !(YGO_SKIP & 2); k += 64) {
-      const uint32_t key = my_rowkey[k];
-      const int ti = key == 0xffffffffu ? -1 : spec_slot(key, a.max_cards);
-      if (ti >= 0 && my_spec[ti] != my_krow[k]) dup = true;
-    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[ti_of[it]] != row1_of[it]) dup = true;
     dup = __any(dup);
     // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
     if (!no_options && !(YGO_SKIP & 4)) {
