@@ -206,6 +206,16 @@ __device__ __forceinline__ uint32_t lane_word(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
 
+// The kernel arguments, re-read from the kernarg segment at the point of use (scalar loads) and
+// laundered so that the compiler cannot merge the read with the copy it made at kernel entry:
+// 17 output pointers held live across the whole kernel cost ~60 spilled SGPRs.
+typedef const __attribute__((address_space(4))) Args* KArgs;
+__device__ __forceinline__ KArgs late_args() {
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const Carve& cv = a.cv;
@@ -239,15 +249,16 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
 
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
-    uint8_t* g_cards = a.out.cards + env * (int64_t)(R * 39);
-    uint8_t* g_actions = a.out.actions + env * (int64_t)(a.max_options * nf);
-    uint8_t* g_hact = a.out.h_actions + env * (int64_t)hist_bytes;
-    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(a.out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
+    KArgs ka = late_args();
+    uint8_t* g_cards = ka->out.cards + env * (int64_t)(R * 39);
+    uint8_t* g_actions = ka->out.actions + env * (int64_t)(a.max_options * nf);
+    uint8_t* g_hact = ka->out.h_actions + env * (int64_t)hist_bytes;
+    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(ka->out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
     if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
     wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
     wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
     wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
-    if (lane < 8) a.out.global[env * 8 + lane] = my_global[lane];
+    if (lane < 8) ka->out.global[env * 8 + lane] = my_global[lane];
   };
 
   // Per env, in this order:
@@ -262,14 +273,18 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   //   H  rows, options, history (LDS only), then the images leave the CU
   {
     bool bad = false;
-    uint8_t* g_cards = a.out.cards + e * (int64_t)(R * 39);
-    uint8_t* my_cards = lds + arena + cv.cards + (int)((uintptr_t)g_cards & 15);
-    uint8_t* g_actions0 = a.out.actions + e * (int64_t)(a.max_options * nf);
-    uint8_t* g_hact0 = a.out.h_actions + e * (int64_t)hist_bytes;
-    uint8_t* g_hcids0 = reinterpret_cast<uint8_t*>(a.out.h_card_ids + e * (int64_t)(a.max_options * a.mms));
-    uint8_t* my_actions = lds + arena + cv.actions + (int)((uintptr_t)g_actions0 & 15);
-    uint8_t* my_hact = lds + arena + cv.hact + (int)((uintptr_t)g_hact0 & 15);
-    uint16_t* my_hcids = reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((uintptr_t)g_hcids0 & 14));
+    // LDS offsets congruent to the images' destinations modulo 16 (only the low bits matter here)
+    uint8_t *my_cards, *my_actions, *my_hact;
+    uint16_t* my_hcids;
+    {
+      KArgs ka = late_args();
+      const uint32_t e4 = (uint32_t)e & 15u;
+      my_cards = lds + arena + cv.cards + (int)(((uint32_t)(uintptr_t)ka->out.cards + e4 * (uint32_t)(R * 39)) & 15u);
+      my_actions = lds + arena + cv.actions + (int)(((uint32_t)(uintptr_t)ka->out.actions + e4 * (uint32_t)(a.max_options * nf)) & 15u);
+      my_hact = lds + arena + cv.hact + (int)(((uint32_t)(uintptr_t)ka->out.h_actions + e4 * (uint32_t)hist_bytes) & 15u);
+      my_hcids = reinterpret_cast<uint16_t*>(
+          lds + arena + cv.hcids + (int)(((uint32_t)(uintptr_t)ka->out.h_card_ids + e4 * (uint32_t)(a.max_options * a.mms * 2)) & 14u));
+    }
 
     wave_zero16(lds, arena + cv.actions, cv.zero_bytes - cv.actions, lane);
     // ---- A ----
@@ -294,17 +309,20 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     const bool no_options = n_opt == 0;                // early-out of WriteState (:1837-1841)
     if (n_opt > a.max_options) n_opt = a.max_options;  // options_.resize (:1849-1851)
 
-    // segments: 2 players x 7 locations (:1510-1519), walked with scalar counters. Each lane picks
-    // up, for its cards k = lane + 64*it, the last listed segment starting at or before k: packed
-    // as row delta (r - k, bits 0..12, biased by 4096) | segment << 13 | "fits" << 17. The three
-    // locations that can be hidden (opponent DECK, HAND, EXTRA) are remembered for step E.
-    int n_cards = 0;
-    uint32_t segv[4] = {0, 0, 0, 0};
+    // segments: 2 players x 7 locations (:1510-1519), walked with scalar counters only. The listed
+    // cards of player pi=0 sit in rows equal to their card index; those of pi=1 are all shifted by
+    // ONE constant (rows of the hidden DECK / HAND in front of them; the hidden EXTRA comes last),
+    // so a lane needs no per-segment search: pi = (k >= n0), r = k + (pi ? shift1 : 0). A segment
+    // that would overrun max_cards rows (the reference has no bound: a buffer overrun there) and
+    // every later one of that player are left out and the batch is flagged: k < fit_end[pi].
+    // [hand1_lo, hand1_hi) is the opponent's listed HAND (the reveal rule, :1541-1545).
+    int n_cards = 0, n0 = 0, shift1 = 0, fit_end0 = 0, fit_end1 = 0, hand1_lo = 0, hand1_hi = 0;
     int ph_row[3] = {0, 0, 0}, ph_cnt[3] = {0, 0, 0};
     if (!no_options) {
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         int row = pi * a.max_cards;
+        if (pi == 1) { n0 = n_cards; fit_end1 = n_cards; }
 #pragma unroll
         for (int li = 0; li < 7; ++li) {
           const int s = pi * 7 + li;
@@ -312,19 +330,16 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           bool hidden = (li == 0 || li == 1 || li == 6);
           if (li == 1 && revealed_any) hidden = false;  // :1522-1525
           const bool count_only = pi == 1 && hidden;
-          // the reference has no bound; more rows than max_cards is a buffer overrun there: such a
-          // segment is left out and the batch is flagged
           const bool fits = row + cnt <= (pi + 1) * a.max_cards;
           if (!fits) bad = true;
           if (count_only) {
             const int ph = li == 0 ? 0 : (li == 1 ? 1 : 2);
             ph_row[ph] = row;
             ph_cnt[ph] = fits ? cnt : 0;
-          } else if (cnt > 0) {
-            const uint32_t packed = (uint32_t)(row - n_cards + 4096) | ((uint32_t)s << 13) | ((uint32_t)fits << 17);
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-              if (lane + 64 * it >= n_cards) segv[it] = packed;
+          } else {
+            if (pi == 1 && li == 1) { hand1_lo = n_cards; hand1_hi = n_cards + cnt; }
+            if (pi == 1 && li == 2) shift1 = row - n_cards;  // the same for every listed pi=1 segment
+            if (fits) { if (pi == 0) fit_end0 = n_cards + cnt; else fit_end1 = n_cards + cnt; }
             n_cards += cnt;
           }
           row += cnt;
@@ -396,20 +411,21 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
 
     // ---- C: scalars + Env::Allocate common fields (env.h:196-222) ----
     if (lane == 0) {
+      KArgs ka = late_args();
       const bool done = (w[1] >> 24) != 0;
       const int elapsed = (int)w[3];
-      a.out.env_id[e] = (int)w[2];
-      a.out.penv[e] = (int)w[2];
-      a.out.elapsed[e] = elapsed;
-      a.out.done[e] = done;
-      a.out.reward[e] = __uint_as_float(w[8]);
-      a.out.discount[e] = done ? 0.f : 1.f;
-      a.out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
-      a.out.trunc[e] = done && (elapsed >= a.max_episode_steps);
-      a.out.num_options[e] = no_options ? 1 : n_opt;
-      a.out.to_play[e] = to_play;
-      a.out.is_selfplay[e] = (int)(w[1] & 0xff);
-      a.out.win_reason[e] = (int)w[7];
+      ka->out.env_id[e] = (int)w[2];
+      ka->out.penv[e] = (int)w[2];
+      ka->out.elapsed[e] = elapsed;
+      ka->out.done[e] = done;
+      ka->out.reward[e] = __uint_as_float(w[8]);
+      ka->out.discount[e] = done ? 0.f : 1.f;
+      ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
+      ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
+      ka->out.num_options[e] = no_options ? 1 : n_opt;
+      ka->out.to_play[e] = to_play;
+      ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
+      ka->out.win_reason[e] = (int)w[7];
     }
     YGO_STAMP(1);
 
@@ -488,21 +504,20 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       ti_of[it] = -1;
       row1_of[it] = 0;
       if (k < n_listed && !(YGO_SKIP & 1)) {
-        const uint32_t sv = segv[it];
+        const uint32_t pi = k >= n0 ? 1u : 0u;
         uint32_t key = 0xffffffffu;
-        if (sv & (1u << 17)) {
+        if (k < (pi ? fit_end1 : fit_end0)) {
           const uint32_t c1 = cw[it][1], c2 = cw[it][2];
           const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
-          const uint32_t seg = (sv >> 13) & 15, pi = seg >= 7 ? 1u : 0u, li = seg - 7 * pi;
-          int r = k + (int)(sv & 8191) - 4096;
-          asm volatile("" : "+v"(r));  // keep the bias out of the byte offsets below
+          const bool in_hand1 = k >= hand1_lo && k < hand1_hi;
+          const int r = k + (pi ? shift1 : 0);
           const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
           const uint32_t lid = (loc7 != 0 && (loc7 & (loc7 - 1)) == 0 && loc7 <= 0x40) ? (uint32_t)__ffs(loc7) : 0u;  // location2id
           // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
           const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * pos)) & 0xf : 0xfu;
           const bool known = (tq[it].y & kEntryValid) && tq[it].x == cw[it][0];
           bool hide = pi != 0 && (pos & 0xa) != 0 &&                                   // POS_FACEDOWN (:1540)
-                      !(li == 1 && seq < 64 && ((hand_mask >> seq) & 1ull));           // revealed (:1541-1545)
+                      !(in_hand1 && seq < 64 && ((hand_mask >> seq) & 1ull));          // revealed (:1541-1545)
           hide = (hide && !overlay) || !known;                                         // :1562-1564
           const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
           if (!known || lid == 0 || (!overlay && pid == 0xf) || (!hide && (attr == 0xff || race == 0xff))) bad = true;
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       }
     }
     YGO_STAMP(5);
-    if (__any(bad) && lane == 0) *a.err = 1u;
+    if (__any(bad) && lane == 0) *late_args()->err = 1u;
     wave_fence();
     flush_env(e, lane);
     YGO_STAMP(6);
