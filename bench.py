@@ -62,11 +62,18 @@ def main():
 
   from envpool_amd import capi
 
-  torch.cuda.set_device(local_rank)
-  dev = torch.device("cuda", local_rank)
+  # EP_BENCH_REHEARSE=1: run the N>1 code path on a box with ONE GPU (every rank on cuda:0, gloo
+  # instead of RCCL, stats gathered through host memory). For checking the logic only.
+  rehearse = os.environ.get("EP_BENCH_REHEARSE") == "1"
+  dev_index = 0 if rehearse else local_rank
+  torch.cuda.set_device(dev_index)
+  dev = torch.device("cuda", dev_index)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+    if rehearse:
+      dist.init_process_group("gloo")
+    else:
+      dist.init_process_group("nccl", device_id=dev)
 
   def barrier():
     if world > 1:
@@ -77,7 +84,7 @@ def main():
   N, T = NUM_ENVS, T_FUSED
   K = max(T, (args.steps + T - 1) // T * T)
   W = (args.warmup + T - 1) // T * T
-  pool = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=local_rank, env_id_offset=rank * N,
+  pool = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=dev_index, env_id_offset=rank * N,
                          ring_depth=2 * T)
   h = pool.handle
 
@@ -111,8 +118,17 @@ def main():
     if world > 1:
       check(L.ep_pool_episode_stats_async(h, st_ret.data_ptr(), st_len.data_ptr(), None,
                                           torch.cuda.current_stream().cuda_stream))
-      dist.all_gather_into_tensor(g_ret, st_ret)
-      dist.all_gather_into_tensor(g_len, st_len)
+      if rehearse:
+        torch.cuda.current_stream().synchronize()
+        parts = [torch.zeros(N, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, st_ret.cpu())
+        g_ret.copy_(torch.cat(parts))
+        parts = [torch.zeros(N, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(parts, st_len.cpu())
+        g_len.copy_(torch.cat(parts))
+      else:
+        dist.all_gather_into_tensor(g_ret, st_ret)
+        dist.all_gather_into_tensor(g_len, st_len)
 
   def run_fused(n_steps):
     rounds = n_steps // T
@@ -144,7 +160,7 @@ def main():
   check(L.ep_pool_set_timing(h, 0))
   elapsed = t1 - t0
   if world > 1:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   kern_us = tot.value / max(1, cnt.value)  # average rollout-kernel duration (HIP events)
@@ -160,14 +176,19 @@ def main():
       check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
       check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
     check(L.ep_pool_sync(h))
-    check(L.ep_pool_set_timing(h, 1))
-    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
     s0 = time.perf_counter()
     for _ in range(ks):
       check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
       check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
     check(L.ep_pool_sync(h))
     s1 = time.perf_counter()
+    # kernel duration from HIP events in a separate short pass (the events cost host time)
+    check(L.ep_pool_set_timing(h, 1))
+    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    for _ in range(64):
+      check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(batch)))
+    check(L.ep_pool_sync(h))
     check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
     check(L.ep_pool_set_timing(h, 0))
     k1_us = tot.value / max(1, cnt.value)

@@ -82,6 +82,9 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.rowkey_stride = al16(R * 4 + R);  // key of listed card k (u32), then its row (u8)
   c.rowkey = o;  o += c.rowkey_stride;
   c.stage = c.cards;  // the record lands (LDS-DMA) where the card image is built afterwards
+#ifdef YGO_LDS_PAD
+  o += YGO_LDS_PAD;  // diagnostic builds: lower the occupancy to see how throughput follows it
+#endif
   c.wave_stride = o;
   c.total = o * kGroup;
   return c;
