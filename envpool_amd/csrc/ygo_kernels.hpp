@@ -275,7 +275,8 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   //   F  probes settled
   //   H  rows, options, history (LDS only), then the images leave the CU
   {
-    bool bad = false;
+    bool bad_u = false;   // raised in wave-uniform code
+    uint32_t badv = 0;    // raised per lane (a VGPR flag: no exec-mask bookkeeping around it)
     // LDS offsets congruent to the images' destinations modulo 16 (only the low bits matter here)
     uint8_t *my_cards, *my_actions, *my_hact;
     uint16_t* my_hcids;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           if (li == 1 && revealed_any) hidden = false;  // :1522-1525
           const bool count_only = pi == 1 && hidden;
           const bool fits = row + cnt <= (pi + 1) * a.max_cards;
-          if (!fits) bad = true;
+          if (!fits) bad_u = true;
           if (count_only) {
             const int ph = li == 0 ? 0 : (li == 1 ? 1 : 2);
             ph_row[ph] = row;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         const uint32_t phase = w[6];
         ft((int)(to_play == 0 ? w[4] : w[5]), my_global[0], my_global[1]);
         ft((int)(to_play == 0 ? w[5] : w[4]), my_global[2], my_global[3]);
-        if (phase == 0 || (phase & (phase - 1)) != 0 || phase > 0x200) bad = true;
+        if (phase == 0 || (phase & (phase - 1)) != 0 || phase > 0x200) badv = 1;
         else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
         my_global[5] = to_play == 0 ? 1 : 0;
         my_global[6] = to_play == turn_player ? 1 : 0;
@@ -512,28 +513,29 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         if (k < (pi ? fit_end1 : fit_end0)) {
           const uint32_t c1 = cw[it][1], c2 = cw[it][2];
           const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
-          const bool in_hand1 = k >= hand1_lo && k < hand1_hi;
+          const bool in_hand1 = (k >= hand1_lo) & (k < hand1_hi);
           const int r = k + (pi ? shift1 : 0);
           const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
-          const uint32_t lid = (loc7 != 0 && (loc7 & (loc7 - 1)) == 0 && loc7 <= 0x40) ? (uint32_t)__ffs(loc7) : 0u;  // location2id
+          // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
+          const bool loc_ok = (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
+          const uint32_t lid = loc_ok ? (uint32_t)__ffs(loc7) : 0u;  // location2id
           // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
-          const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * pos)) & 0xf : 0xfu;
-          const bool known = (tq[it].y & kEntryValid) && tq[it].x == cw[it][0];
-          bool hide = pi != 0 && (pos & 0xa) != 0 &&                                   // POS_FACEDOWN (:1540)
-                      !(in_hand1 && seq < 64 && ((hand_mask >> seq) & 1ull));          // revealed (:1541-1545)
-          hide = (hide && !overlay) || !known;                                         // :1562-1564
+          const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * (pos & 15))) & 0xf : 0xfu;
+          const bool known = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
+          const bool revealed = in_hand1 & (seq < 64) & (((hand_mask >> (seq & 63)) & 1ull) != 0);  // :1541-1545
+          bool hide = (pi != 0) & ((pos & 0xa) != 0) & !revealed;                                   // POS_FACEDOWN (:1540)
+          hide = (hide & (overlay == 0)) | !known;                                                  // :1562-1564
           const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
-          if (!known || lid == 0 || (!overlay && pid == 0xf) || (!hide && (attr == 0xff || race == 0xff))) bad = true;
-          uint32_t level = tlevel;
-          if ((c2 >> 24) == 0) {  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
-            if (c2 & 0xff) level = c2 & 0xff;
-            if ((c2 >> 8) & 0xff) level = (c2 >> 8) & 0xff;
-            if ((c2 >> 16) & 0xff) level = (c2 >> 16) & 0xff;
-          }
+          badv |= (!known | !loc_ok | ((overlay == 0) & (pid == 0xf)) | (!hide & ((attr == 0xff) | (race == 0xff)))) ? 1u : 0u;
+          const uint32_t lv = c2 & 0xff, rk = (c2 >> 8) & 0xff, lk = (c2 >> 16) & 0xff;
+          uint32_t level = lv ? lv : tlevel;  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
+          level = rk ? rk : level;
+          level = lk ? lk : level;
+          level = (c2 >> 24) ? tlevel : level;  // an overlay material shows its static level
           // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
           const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][4] & 0xffff;
           const uint32_t show = hide ? 0u : 0xffffffffu;
-          const uint32_t b3 = (loc7 == 0x04 || loc7 == 0x08 || loc7 == 0x10) ? seq + 1 : 0u;  // :1573-1578
+          const uint32_t b3 = ((loc7 == 0x04) | (loc7 == 0x08) | (loc7 == 0x10)) ? seq + 1 : 0u;  // :1573-1578
           const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
           const uint32_t w0 = (((cid >> 8) | ((cid & 0xff) << 8)) & show) | (lid << 16) | ((b3 & 0xff) << 24);
           const uint32_t w1 = (ctrl != (uint32_t)to_play ? 1u : 0u) | (b5 << 8) | (overlay << 16) | (((attr == 0xff ? 0u : attr) << 24) & show);
@@ -554,14 +556,11 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           }
           const uint32_t suf = overlay ? (pos + 1) & 0xff : 0u;
           key = pi | (loc7 << 8) | (seq << 16) | (suf << 24);
-          int ti = -1;
-          if (lid != 0) {
-            if (suf == 0) {
-              if (seq < (uint32_t)a.max_cards) ti = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
-            } else if (loc7 == 0x04 && seq < 8 && suf <= 8) {
-              ti = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
-            }
-          }
+          const int ti_plain = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
+          const int ti_over = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
+          const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
+          const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
+          const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
           if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
           my_krow[k] = (uint8_t)(r + 1);  // row of listed card k
           ti_of[it] = ti;
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
             for (int k = 0; k < n_listed; ++k)
               if (my_rowkey[k] == key) idx = max(idx, (int)my_krow[k]);  // last row wins (:1549)
           }
-          if (idx == 0) bad = true;  // spec2index.at(spec) throws
+          badv |= idx == 0 ? 1u : 0u;  // spec2index.at(spec) throws
           arow[2 * j] = (uint8_t)(idx >> 8);
           arow[2 * j + 1] = (uint8_t)(idx & 0xff);
           // read back from the images, literally: low byte only (Q7), stop at the first zero
@@ -634,7 +633,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       }
     }
     YGO_STAMP(5);
-    if (__any(bad) && lane == 0) *late_args()->err = 1u;
+    if ((bad_u || __any(badv != 0)) && lane == 0) *late_args()->err = 1u;
     wave_fence();
     flush_env(e, lane);
     YGO_STAMP(6);
