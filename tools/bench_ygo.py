@@ -66,36 +66,76 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
              "achieved_GBps": alg_per_rec * n_big / (k_us * 1e-6) / 1e9, "frac_of_8TBps": alg_per_rec * n_big / (k_us * 1e-6) / 8e12}
   enc.close()
 
-  # config 3: 1024 host records per step through the pinned pipeline (copy of k+1 under kernel of k)
-  cfg3 = capi_ygo.default_config(max_batch=n_cfg3, ring_depth=4)
-  enc3 = capi_ygo.YgoEncoderC(cfg3, table, len(table))
-  h3 = enc3.handle
-  rec3 = np.ascontiguousarray(recs[:n_cfg3])
-  steps = 400
-  for _ in range(8):
-    L.ep_ygo_submit(h3, rec3.ctypes.data, n_cfg3)
-    L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b))
-  L.ep_ygo_set_timing(h3, 1)
-  L.ep_ygo_kernel_time_us(h3, C.byref(tot), C.byref(cnt), 1)
-  w0 = time.perf_counter()
-  inflight = 0
-  for s in range(steps):
-    assert L.ep_ygo_submit(h3, rec3.ctypes.data, n_cfg3) == 0
-    inflight += 1
-    if inflight == 3:
-      assert L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  # host records through the pinned pipeline (copy of batch k+1 under the kernel of batch k):
+  # config 3 (1024 records per step) and the per-GPU share of config 5 (512-record batches)
+  def pipeline(n_rec, steps=400):
+    cfgp = capi_ygo.default_config(max_batch=n_rec, ring_depth=4)
+    encp = capi_ygo.YgoEncoderC(cfgp, table, len(table))
+    hp = encp.handle
+    recp = np.ascontiguousarray(recs[:n_rec])
+    for _ in range(8):
+      L.ep_ygo_submit(hp, recp.ctypes.data, n_rec)
+      L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b))
+    L.ep_ygo_set_timing(hp, 1)
+    L.ep_ygo_kernel_time_us(hp, C.byref(tot), C.byref(cnt), 1)
+    w0 = time.perf_counter()
+    inflight = 0
+    for s in range(steps):
+      assert L.ep_ygo_submit(hp, recp.ctypes.data, n_rec) == 0
+      inflight += 1
+      if inflight == 3:
+        assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+        inflight -= 1
+    while inflight:
+      assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
       inflight -= 1
-  while inflight:
-    assert L.ep_ygo_collect(h3, capi.EP_MEM_DEVICE, C.byref(b)) in ok
-    inflight -= 1
-  w1 = time.perf_counter()
-  L.ep_ygo_kernel_time_us(h3, C.byref(tot), C.byref(cnt), 1)
-  cfg3_res = {"records_per_step": n_cfg3, "steps": steps, "encodes_per_s_wall_pcie_inclusive": n_cfg3 * steps / (w1 - w0),
-              "us_per_step_wall": (w1 - w0) / steps * 1e6, "kernel_us": tot.value / max(1, cnt.value),
-              "record_stride_bytes": int(stride)}
-  enc3.close()
+    w1 = time.perf_counter()
+    L.ep_ygo_kernel_time_us(hp, C.byref(tot), C.byref(cnt), 1)
+    # in-place form: the producers write records straight into the pinned slot
+    # (ep_ygo_acquire_slot / ep_ygo_commit_slot), so the staging memcpy of submit disappears
+    slot = C.c_void_p()
+    for _ in range(4):  # fill every slot of the ring once
+      assert L.ep_ygo_acquire_slot(hp, C.byref(slot)) == 0
+      C.memmove(slot, recp.ctypes.data, recp.nbytes)
+      assert L.ep_ygo_commit_slot(hp, n_rec) == 0
+      assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    i0 = time.perf_counter()
+    inflight = 0
+    for s in range(steps):
+      assert L.ep_ygo_acquire_slot(hp, C.byref(slot)) == 0
+      assert L.ep_ygo_commit_slot(hp, n_rec) == 0
+      inflight += 1
+      if inflight == 3:
+        assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+        inflight -= 1
+    while inflight:
+      assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      inflight -= 1
+    i1 = time.perf_counter()
+    inplace_us = (i1 - i0) / steps * 1e6
+    encp.close()
+    # the H2D copy alone, same bytes, pinned source: what the pipeline cannot go below
+    src = torch.from_numpy(recp).pin_memory()
+    dst = torch.empty_like(src, device="cuda:0")
+    for _ in range(4):
+      dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(100):
+      dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    copy_us = (time.perf_counter() - c0) / 100 * 1e6
+    step_us = (w1 - w0) / steps * 1e6
+    k_us = tot.value / max(1, cnt.value)
+    return {"records_per_step": n_rec, "steps": steps, "encodes_per_s_wall_pcie_inclusive": n_rec * steps / (w1 - w0),
+            "us_per_step_wall": step_us, "kernel_us": k_us, "h2d_copy_us": copy_us,
+            "us_per_step_wall_in_place": inplace_us, "encodes_per_s_in_place_pcie_inclusive": n_rec / (inplace_us * 1e-6),
+            "overlap_efficiency": max(copy_us, k_us) / inplace_us, "record_stride_bytes": int(stride)}
 
-  res = {"large_batch": big_res, "config3_host_pipeline": cfg3_res,
+  cfg3_res = pipeline(n_cfg3)
+  cfg5_res = pipeline(512)
+
+  res = {"large_batch": big_res, "config3_host_pipeline": cfg3_res, "config5_per_gpu_host_pipeline": cfg5_res,
          "host_emit_records_per_s_1core": n_gen / emit_s}
   if cpu_seconds > 0:
     from oracle import ygo_oracle

@@ -1,3 +1,4 @@
+"""Host-side cost of one send + blocking recv per lockstep step (GPU box): where the ~15 us go."""
 import ctypes as C, time, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
