@@ -357,20 +357,17 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // until the code that needs a field: unpacked early they cost 60 more VGPRs.
     uint32_t cw[4][5];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack | defense
     uint32_t mw[11];     // ygo_option: feats[0..8], n_specs, pad | spec_key[8]
+    // (read unconditionally, index clamped into the array: a lane beyond the listed cards / the
+    // options holds words it never uses - the emitter zero-fills the unused tail, so those lanes
+    // all probe the hash slot of code 0)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + min(lane + 64 * it, R - 1) * 5;
 #pragma unroll
-      for (int d = 0; d < 5; ++d) cw[it][d] = 0;
-      if (lane + 64 * it < n_listed) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + (lane + 64 * it) * 5;
-#pragma unroll
-        for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
-      }
+      for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
     }
-#pragma unroll
-    for (int d = 0; d < 11; ++d) mw[d] = 0;
-    if (lane < n_opt) {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + lane * 11;
+    {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * 11;
 #pragma unroll
       for (int d = 0; d < 11; ++d) mw[d] = src[d];
     }
@@ -459,6 +456,33 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
         my_global[5] = to_play == 0 ? 1 : 0;
         my_global[6] = to_play == turn_player ? 1 : 0;
+      }
+    }
+    // (work that needs no card data goes here, under the latency of the hash probes)
+    // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
+    if (!no_options && !(YGO_SKIP & 4)) {
+      const int shift = ha_p * nf;
+#pragma unroll
+      for (int ww = 0; ww < 2; ++ww) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int src = 256 * ww + 4 * lane + bb;  // ring byte held by this lane
+          const uint8_t v = (uint8_t)(hw[ww] >> (8 * bb));
+          if (src < hist_bytes && v) {
+            int dst = src - shift;
+            if (dst < 0) dst += hist_bytes;
+            my_hact[dst] = v;
+          }
+        }
+      }
+    }
+    // the nine spec-independent feature bytes of each option (columns 2*mms .. 2*mms+8)
+    if (lane < n_opt && !(YGO_SKIP & 8)) {
+      uint8_t* frow = my_actions + lane * nf + 2 * a.mms;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
+        if (f) frow[k] = f;
       }
     }
     YGO_STAMP(2);
@@ -578,23 +602,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     for (int it = 0; it < 4; ++it)
       if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[ti_of[it]] != row1_of[it]) dup = true;
     dup = __any(dup);
-    // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
-    if (!no_options && !(YGO_SKIP & 4)) {
-      const int shift = ha_p * nf;
-#pragma unroll
-      for (int ww = 0; ww < 2; ++ww) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int src = 256 * ww + 4 * lane + bb;  // ring byte held by this lane
-          const uint8_t v = (uint8_t)(hw[ww] >> (8 * bb));
-          if (src < hist_bytes && v) {
-            int dst = src - shift;
-            if (dst < 0) dst += hist_bytes;
-            my_hact[dst] = v;
-          }
-        }
-      }
-    }
     // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
     for (int d = 0; d < 11; ++d) asm volatile("" : "+v"(mw[d]));
@@ -625,11 +632,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
             my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
           }
         }
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
-        if (f) arow[2 * a.mms + k] = f;
       }
     }
     YGO_STAMP(5);
