@@ -269,10 +269,10 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   //      card image is built later; meanwhile the small images and the spec table are zeroed
   //      (the reference's fresh zero-filled StateBuffer, array.h:77-81)
   //   B  header -> scalars, packed card / option / history words -> lanes, hash probes issued
-  //   C  scalar outputs
   //   D  the landing area becomes the zeroed card image
-  //   E  placeholder rows, obs:global_
+  //   E  placeholder rows, obs:global_, history rotation, option feature bytes
   //   F  probes settled
+  //   C  scalar outputs (after F: VMEM retires in issue order)
   //   H  rows, options, history (LDS only), then the images leave the CU
   {
     bool bad_u = false;   // raised in wave-uniform code
@@ -410,26 +410,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     }
     YGO_STAMP(0);
 
-    // ---- C: scalars + Env::Allocate common fields (env.h:196-222) ----
-    if (lane == 0) {
-      KArgs ka = late_args();
-      const bool done = (w[1] >> 24) != 0;
-      const int elapsed = (int)w[3];
-      ka->out.env_id[e] = (int)w[2];
-      ka->out.penv[e] = (int)w[2];
-      ka->out.elapsed[e] = elapsed;
-      ka->out.done[e] = done;
-      ka->out.reward[e] = __uint_as_float(w[8]);
-      ka->out.discount[e] = done ? 0.f : 1.f;
-      ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
-      ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
-      ka->out.num_options[e] = no_options ? 1 : n_opt;
-      ka->out.to_play[e] = to_play;
-      ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
-      ka->out.win_reason[e] = (int)w[7];
-    }
     YGO_STAMP(1);
-
     // ---- D ----
     wave_fence();
     wave_zero16(lds, arena + cv.cards, cv.actions, lane);
@@ -515,6 +496,28 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     for (int it = 0; it < 4; ++it)
       asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
     YGO_STAMP(3);
+
+    // ---- C: scalars + Env::Allocate common fields (env.h:196-222). Issued only now: VMEM retires
+    // in issue order, so stores in front of the probe wait above would have put their
+    // acknowledgement latency into it ----
+    if (lane == 0) {
+      KArgs ka = late_args();
+      const bool done = (w[1] >> 24) != 0;
+      const int elapsed = (int)w[3];
+      ka->out.env_id[e] = (int)w[2];
+      ka->out.penv[e] = (int)w[2];
+      ka->out.elapsed[e] = elapsed;
+      ka->out.done[e] = done;
+      ka->out.reward[e] = __uint_as_float(w[8]);
+      ka->out.discount[e] = done ? 0.f : 1.f;
+      ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
+      ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
+      ka->out.num_options[e] = no_options ? 1 : n_opt;
+      ka->out.to_play[e] = to_play;
+      ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
+      ka->out.win_reason[e] = (int)w[7];
+    }
+
 
     // ---- H ----
     // ---- obs:cards_ : one lane per LISTED card (:1508-1603), written branch-free: the 14 leading
