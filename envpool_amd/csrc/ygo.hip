@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -68,7 +69,7 @@ struct ep_ygo_encoder {
   hipStream_t stream = nullptr, copy_stream = nullptr;
   ygk::HashEntry* d_table = nullptr;
   ygk::HashAux* d_table_aux = nullptr;
-  uint32_t table_mask = 0;
+  uint32_t table_mask = 0, table_mul_b = 0;
   std::vector<Slot> slots;
   uint32_t* h_err = nullptr;  // [ring] host-mapped
   uint32_t* d_err = nullptr;
@@ -117,6 +118,7 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
   a.table = e->d_table;
   a.table_aux = e->d_table_aux;
   a.table_mask = e->table_mask;
+  a.table_mul_b = e->table_mul_b;
   a.max_cards = e->cfg.max_cards;
   a.max_options = e->cfg.max_options;
   a.n_hist = e->cfg.n_history_actions;
@@ -291,35 +293,69 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
   if (!e || (!cards && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad card table");
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
-  uint32_t cap = 64;
-  while (cap < (uint32_t)n * 2u) cap <<= 1;
-  std::vector<ygk::HashEntry> tab(cap);
-  std::vector<ygk::HashAux> aux(cap);
-  memset(tab.data(), 0, sizeof(ygk::HashEntry) * cap);
-  memset(aux.data(), 0, sizeof(ygk::HashAux) * cap);
-  for (int i = 0; i < n; ++i) {
-    const ygo_card_data& c = cards[i];
-    ygk::HashEntry h;
-    memset(&h, 0, sizeof(h));
-    h.code = c.code;
-    h.type = ygk::kEntryValid;
-    for (int j = 0; j < 25; ++j)  // type_to_ids order (ygopro.h:635-642)
-      if (c.type & ygk::type_bit(j)) h.type |= 1u << j;
-    h.card_id = c.card_id;
-    h.level = (uint8_t)c.level;
-    // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7
-    h.attr_id = 0xff;
-    if (c.attribute == 0) h.attr_id = 0;
-    else if ((c.attribute & (c.attribute - 1)) == 0 && c.attribute <= 0x40) h.attr_id = (uint8_t)(__builtin_ctz(c.attribute) + 1);
-    // race2id (:575-605): {0, bit0..bit25} -> 0..26
-    h.race_id = 0xff;
-    if (c.race == 0) h.race_id = 0;
-    else if ((c.race & (c.race - 1)) == 0 && c.race <= (1u << 25)) h.race_id = (uint8_t)(__builtin_ctz(c.race) + 1);
-    uint32_t slot = (ygk::hash_code(c.code) >> 7) & (cap - 1);
-    while ((tab[slot].type & ygk::kEntryValid) && tab[slot].code != c.code) slot = (slot + 1) & (cap - 1);
-    tab[slot] = h;  // a repeated code keeps the last entry, like map[code] = ...
-    aux[slot].attack = c.attack;
-    aux[slot].defense = c.defense;
+  // entries first (a repeated code keeps the last one, like map[code] = ...)
+  std::vector<ygk::HashEntry> ent;
+  std::vector<ygk::HashAux> ent_aux;
+  {
+    std::unordered_map<uint32_t, size_t> last;
+    for (int i = 0; i < n; ++i) last[cards[i].code] = (size_t)i;
+    for (int i = 0; i < n; ++i) {
+      const ygo_card_data& c = cards[i];
+      if (last[c.code] != (size_t)i) continue;
+      ygk::HashEntry h;
+      memset(&h, 0, sizeof(h));
+      h.code = c.code;
+      h.type = ygk::kEntryValid;
+      for (int j = 0; j < 25; ++j)  // type_to_ids order (ygopro.h:635-642)
+        if (c.type & ygk::type_bit(j)) h.type |= 1u << j;
+      h.card_id = c.card_id;
+      h.level = (uint8_t)c.level;
+      // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7
+      h.attr_id = 0xff;
+      if (c.attribute == 0) h.attr_id = 0;
+      else if ((c.attribute & (c.attribute - 1)) == 0 && c.attribute <= 0x40) h.attr_id = (uint8_t)(__builtin_ctz(c.attribute) + 1);
+      // race2id (:575-605): {0, bit0..bit25} -> 0..26
+      h.race_id = 0xff;
+      if (c.race == 0) h.race_id = 0;
+      else if ((c.race & (c.race - 1)) == 0 && c.race <= (1u << 25)) h.race_id = (uint8_t)(__builtin_ctz(c.race) + 1);
+      ent.push_back(h);
+      ent_aux.push_back(ygk::HashAux{c.attack, c.defense});
+    }
+  }
+  // cuckoo build: every code ends up in slot_a or slot_b. Load <= 0.4; on a cycle try the next
+  // multiplier for the second function, then a larger table.
+  uint32_t cap = 64, mul_b = 0;
+  while (cap < (uint32_t)ent.size() * 5u / 2u) cap <<= 1;
+  std::vector<ygk::HashEntry> tab;
+  std::vector<ygk::HashAux> aux;
+  static const uint32_t kMulB[8] = {0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0x9E3779B1u, 0xD6E8FEB9u, 0xCC9E2D51u, 0x1B873593u};
+  for (int attempt = 0;; ++attempt) {
+    if (attempt == 64) return fail(EP_ERR_INVALID, "card table: no two-choice placement found");
+    if (attempt && attempt % 8 == 0) cap <<= 1;
+    mul_b = kMulB[attempt % 8];
+    tab.assign(cap, ygk::HashEntry{});
+    aux.assign(cap, ygk::HashAux{0, 0});
+    bool ok = true;
+    for (size_t i = 0; i < ent.size() && ok; ++i) {
+      ygk::HashEntry h = ent[i];
+      ygk::HashAux x = ent_aux[i];
+      uint32_t slot = ygk::slot_a(h.code, cap - 1);
+      ok = false;
+      for (int kick = 0; kick < 512; ++kick) {
+        if (!(tab[slot].type & ygk::kEntryValid)) {
+          tab[slot] = h;
+          aux[slot] = x;
+          ok = true;
+          break;
+        }
+        std::swap(h, tab[slot]);
+        std::swap(x, aux[slot]);
+        // the evicted entry moves to its OTHER slot
+        const uint32_t sa = ygk::slot_a(h.code, cap - 1), sb = ygk::slot_b(h.code, mul_b, cap - 1);
+        slot = slot == sa ? sb : sa;
+      }
+    }
+    if (ok) break;
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
   (void)hipFree(e->d_table);
@@ -331,6 +367,7 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
   HIP_TRY(hipMemcpy(e->d_table, tab.data(), sizeof(ygk::HashEntry) * cap, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_table_aux, aux.data(), sizeof(ygk::HashAux) * cap, hipMemcpyHostToDevice));
   e->table_mask = cap - 1;
+  e->table_mul_b = mul_b;
   return EP_OK;
 }
 

@@ -42,7 +42,11 @@ struct HashAux {  // same slot as the entry; only overlay materials need it (sta
   int32_t attack, defense;
 };
 
-__host__ __device__ inline uint32_t hash_code(uint32_t code) { return code * 2654435761u; }
+// Two-choice (cuckoo) hashing: a code lives in slot_a or slot_b, both known from the code alone,
+// so a lookup is two independent loads and never a dependent chain (with linear probing almost
+// every wave had some lane in a collision chain, each step a full L2 round trip for all 64).
+__host__ __device__ inline uint32_t slot_a(uint32_t code, uint32_t mask) { return ((code * 2654435761u) >> 7) & mask; }
+__host__ __device__ inline uint32_t slot_b(uint32_t code, uint32_t mul_b, uint32_t mask) { return (((code ^ (code >> 15)) * mul_b) >> 9) & mask; }
 
 struct Outs {
   int32_t* env_id; int32_t* penv; int32_t* elapsed; uint8_t* done; float* reward; float* discount;
@@ -97,6 +101,7 @@ struct Args {
   const HashEntry* table;
   const HashAux* table_aux;
   uint32_t table_mask;  // capacity - 1
+  uint32_t table_mul_b; // multiplier of the second hash function (chosen by the host build)
   int32_t max_cards, max_options, n_hist, mms, nf, max_episode_steps;
   Carve cv;  // LDS arena and record layout, computed once on the host
   Outs out;
@@ -382,22 +387,17 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // in bounds, and ignores the answer - a conditional load would make the compiler wait for
     // each in turn.) An overlay material shows its static attack / defense (c_get_card copy,
     // :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
-    uint4 tq[4];  // HashEntry: code | type | card_id, level, attr_id | race_id
+    uint4 tq[4], tq2[4];  // HashEntry: code | type | card_id, level, attr_id | race_id (both candidate slots)
     const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const uint32_t slot0 = (hash_code(cw[it][0]) >> 7) & a.table_mask;
-      if (!(YGO_SKIP & (32 | 64))) tq[it] = table_q[slot0];
+      if (!(YGO_SKIP & (32 | 64))) {
+        tq[it] = table_q[slot_a(cw[it][0], a.table_mask)];
+        tq2[it] = table_q[slot_b(cw[it][0], a.table_mul_b, a.table_mask)];
+      }
       if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
-        tq[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
-      if (YGO_SKIP & 32) tq[it] = make_uint4(0, 0, 0, 0);
-    }
-    uint2 ax[4];  // HashAux of the lane's overlay materials
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      ax[it] = make_uint2(0, 0);
-      if ((cw[it][2] >> 24) && !(YGO_SKIP & (32 | 64)))
-        ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[(hash_code(cw[it][0]) >> 7) & a.table_mask];
+        tq[it] = tq2[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
+      if (YGO_SKIP & 32) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
     }
     // rings longer than 512 bytes: the tail goes from the stage to the image now
     if (hist_bytes > 512 && !no_options) {
@@ -468,28 +468,20 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     }
     YGO_STAMP(2);
 
-    // ---- F: collisions (load factor <= 0.5): keep probing, rarely ----
+    // ---- F: the entry is the candidate whose code matches (neither: the card is unknown). An
+    // overlay material shows its static attack / defense (c_get_card copy, :2109-2114), fetched
+    // from the parallel table now that the slot is known: they replace the (absent) dynamic ones.
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      if (lane + 64 * it < n_listed && (tq[it].y & kEntryValid) && tq[it].x != cw[it][0]) {
-        uint32_t slot = (hash_code(cw[it][0]) >> 7) & a.table_mask;
-        uint4 found = make_uint4(0, 0, 0, 0);
-        for (uint32_t probe = 0; probe < a.table_mask; ++probe) {
-          slot = (slot + 1) & a.table_mask;
-          const uint4 cand = table_q[slot];
-          if (!(cand.y & kEntryValid)) break;
-          if (cand.x == cw[it][0]) { found = cand; break; }
-        }
-        tq[it] = found;
-        if (cw[it][2] >> 24) ax[it] = reinterpret_cast<const uint2*>(a.table_aux)[slot];
+      const bool hit_a = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
+      if (!hit_a) tq[it] = tq2[it];
+      if ((cw[it][2] >> 24) != 0 && lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) {
+        const uint32_t slot = hit_a ? slot_a(cw[it][0], a.table_mask) : slot_b(cw[it][0], a.table_mul_b, a.table_mask);
+        const uint2 x = reinterpret_cast<const uint2*>(a.table_aux)[slot];
+        cw[it][3] = x.x;
+        cw[it][4] = x.y;
       }
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-      if (cw[it][2] >> 24) {
-        cw[it][3] = ax[it].x;
-        cw[it][4] = ax[it].y;
-      }
     // every table read has returned (make the compiler settle them here: a wait for one of them
     // after the prefetch below would also wait for the prefetch)
 #pragma unroll
