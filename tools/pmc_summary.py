@@ -18,7 +18,8 @@ def main():
   out = {"kernel": needle, "min_grid": min_grid}
 
   def keep(r):
-    return needle in r.get("Kernel_Name", "") and int(r.get("Grid_Size", min_grid) or 0) >= min_grid
+    grid = r.get("Grid_Size") or r.get("Grid_Size_X") or min_grid
+    return needle in r.get("Kernel_Name", "") and int(grid) >= min_grid
 
   for path in sorted(glob.glob(os.path.join(root, "**", "*.csv"), recursive=True)):
     with open(path, newline="") as f:
