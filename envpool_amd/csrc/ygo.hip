@@ -35,7 +35,7 @@ Layout make_layout(const ep_ygo_config& c) {
   l.off_cards = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
   l.off_opts = l.off_cards + 2 * c.max_cards * (int)sizeof(ygo_card);
   l.off_opts = (l.off_opts + 15) & ~15;
-  l.stride = (int64_t)align_up((size_t)l.off_opts + (size_t)c.max_options * sizeof(ygo_option));
+  l.stride = (int64_t)align_up((size_t)l.off_opts + (size_t)c.max_options * ygk::option_bytes(c.max_multi_select));
   return l;
 }
 
@@ -546,8 +546,8 @@ int parse_location(const uint8_t* buf, int len, std::vector<ygo_card>* out) {
     c.position = r.u8();
     c.level = (uint8_t)(r.u32() & 0xff);
     c.rank = (uint8_t)(r.u32() & 0xff);
-    c.attack = (int32_t)r.u32();
-    c.defense = (int32_t)r.u32();
+    c.attack = (uint16_t)(r.u32() & 0xffff);
+    c.defense = (uint16_t)(r.u32() & 0xffff);
     if (f & kQueryEquipCard) r.u32();
     const uint32_t n_xyz = r.u32();
     for (uint32_t i = 0; i < n_xyz && r.ok; ++i) {
@@ -567,7 +567,7 @@ int parse_location(const uint8_t* buf, int len, std::vector<ygo_card>* out) {
     r.u32();  // rscale
     c.link = (uint8_t)(r.u32() & 0xff);
     const uint32_t link_marker = r.u32();
-    if (link_marker > 0) c.defense = (int32_t)link_marker;
+    if (link_marker > 0) c.defense = (uint16_t)(link_marker & 0xffff);
     if (!r.ok) return fail(EP_ERR_INVALID, "truncated query_field_card buffer");
     out->push_back(c);
   }
@@ -814,18 +814,20 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
                 cards.size(), 2 * cfg->max_cards);
   memcpy(rec + lay.off_cards, cards.data(), cards.size() * sizeof(ygo_card));
   const int n_opt = std::min(in->n_options, cfg->max_options);
-  ygo_option* opts = (ygo_option*)(rec + lay.off_opts);
+  const size_t opt_bytes = (size_t)ygk::option_bytes(cfg->max_multi_select);
   for (int i = 0; i < n_opt; ++i) {
+    ygo_option_head* oh = (ygo_option_head*)(rec + lay.off_opts + (size_t)i * opt_bytes);
+    uint32_t* keys = (uint32_t*)(oh + 1);
     std::vector<std::string> specs;
     if (!in->options[i]) return fail(EP_ERR_INVALID, "null option string");
-    if ((rc = parse_option(in->msg, in->options[i], opts[i].feats, &specs))) return rc;
+    if ((rc = parse_option(in->msg, in->options[i], oh->feats, &specs))) return rc;
     if ((int)specs.size() > cfg->max_multi_select)
       return fail(EP_ERR_INVALID, "option '%s' references %zu specs, more than max_multi_select", in->options[i], specs.size());
-    opts[i].n_specs = (uint8_t)specs.size();
+    oh->n_specs = (uint8_t)specs.size();
     for (size_t j = 0; j < specs.size(); ++j) {
       // a malformed spec can never be a key of spec2index: give it a key no row carries, so the
       // device reports the same "throw" the reference's .at() would
-      if (!spec_key(specs[j], &opts[i].spec_key[j])) opts[i].spec_key[j] = 0xfffffffeu;
+      if (!spec_key(specs[j], &keys[j])) keys[j] = 0xfffffffeu;
     }
   }
   return EP_OK;

@@ -55,6 +55,8 @@ struct Outs {
 };
 
 __host__ __device__ inline int al16(int x) { return (x + 15) & ~15; }
+// one option of a record: ygo_option_head + max_multi_select spec keys
+__host__ __device__ inline int option_bytes(int mms) { return (int)sizeof(ygo_option_head) + 4 * mms; }
 // per-wave LDS arena (byte offsets inside it, all 16-byte aligned). Each image region has 16
 // spare bytes so that the image can start at its destination's address modulo 16.
 struct Carve {
@@ -72,7 +74,7 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.off_hist = 64;
   c.off_cards = c.off_hist + al16(n_hist * nf);
   c.off_opts = al16(c.off_cards + R * (int)sizeof(ygo_card));
-  c.rec_bytes = al16(c.off_opts + max_options * (int)sizeof(ygo_option));
+  c.rec_bytes = al16(c.off_opts + max_options * option_bytes(mms));
   c.stage_bytes = (c.rec_bytes + 1023) & ~1023;
   int o = 0;
   c.cards = o;   o += max(al16(R * 39) + 16, c.stage_bytes);  // doubles as the record's landing area
@@ -360,21 +362,20 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128, l+192
     // and option l; the history ring is held four bytes per lane. They stay PACKED (raw dwords)
     // until the code that needs a field: unpacked early they cost 60 more VGPRs.
-    uint32_t cw[4][5];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack | defense
-    uint32_t mw[11];     // ygo_option: feats[0..8], n_specs, pad | spec_key[8]
+    uint32_t cw[4][4];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack,defense
+    uint32_t mw[3 + EP_YGO_MAX_SPECS];  // option: feats[0..8], n_specs, pad | spec_key[max_multi_select]
     // (read unconditionally, index clamped into the array: a lane beyond the listed cards / the
     // options holds words it never uses - the emitter zero-fills the unused tail, so those lanes
     // all probe the hash slot of code 0)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_cards) + min(lane + 64 * it, R - 1) * 5;
-#pragma unroll
-      for (int d = 0; d < 5; ++d) cw[it][d] = src[d];
+      const uint4 c4 = reinterpret_cast<const uint4*>(stage + cv.off_cards)[min(lane + 64 * it, R - 1)];  // one 16-byte read
+      cw[it][0] = c4.x; cw[it][1] = c4.y; cw[it][2] = c4.z; cw[it][3] = c4.w;
     }
     {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * 11;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
 #pragma unroll
-      for (int d = 0; d < 11; ++d) mw[d] = src[d];
+      for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = d < 3 + a.mms ? src[d] : 0u;
     }
     uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
     {
@@ -478,15 +479,14 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       if ((cw[it][2] >> 24) != 0 && lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) {
         const uint32_t slot = hit_a ? slot_a(cw[it][0], a.table_mask) : slot_b(cw[it][0], a.table_mul_b, a.table_mask);
         const uint2 x = reinterpret_cast<const uint2*>(a.table_aux)[slot];
-        cw[it][3] = x.x;
-        cw[it][4] = x.y;
+        cw[it][3] = (x.x & 0xffff) | (x.y << 16);
       }
     }
     // every table read has returned (make the compiler settle them here: a wait for one of them
     // after the prefetch below would also wait for the prefetch)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]), "+v"(cw[it][4]) : : "memory");
+      asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]) : : "memory");
     YGO_STAMP(3);
 
     // ---- C: scalars + Env::Allocate common fields (env.h:196-222). Issued only now: VMEM retires
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           level = lk ? lk : level;
           level = (c2 >> 24) ? tlevel : level;  // an overlay material shows its static level
           // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
-          const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][4] & 0xffff;
+          const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][3] >> 16;
           const uint32_t show = hide ? 0u : 0xffffffffu;
           const uint32_t b3 = ((loc7 == 0x04) | (loc7 == 0x08) | (loc7 == 0x10)) ? seq + 1 : 0u;  // :1573-1578
           const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     dup = __any(dup);
     // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
-    for (int d = 0; d < 11; ++d) asm volatile("" : "+v"(mw[d]));
+    for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) asm volatile("" : "+v"(mw[d]));
     if (lane < n_opt && !(YGO_SKIP & 8)) {
       uint8_t* arow = my_actions + lane * nf;
       const int ns = min((int)((mw[2] >> 8) & 0xff), a.mms);

@@ -47,9 +47,9 @@ typedef struct {
  *           | history ring of the to_play player, n_history_actions*n_action_feats bytes,
  *             raw ring order (ygopro.h:1304-1314), padded to 16 B
  *           | ygo_card[2*max_cards]        (only the first sum(loc_count of listed
- *                                           locations) entries are meaningful)
- *           | ygo_option[max_options]
- * padded to a multiple of 256 B: ep_ygo_record_stride(). */
+ *                                           locations) entries are meaningful; the rest are zero)
+ *           | max_options x { ygo_option_head, uint32_t spec_key[max_multi_select] }
+ * padded to a multiple of 256 B: ep_ygo_record_stride() (3328 B at the default config). */
 typedef struct {
   uint8_t to_play;      /* to_play_ (:1281) */
   uint8_t turn_player;  /* tp_ (:1275) */
@@ -86,9 +86,11 @@ typedef struct {
   uint8_t rank;       /* low byte of the queried rank                   (:2094-2097) */
   uint8_t link;       /* low byte of the queried link rating            (:2126-2130) */
   uint8_t is_material;/* 1 for overlay materials: every dynamic field below is absent (:2109-2114) */
-  int32_t attack;     /* queried attack (:2098) */
-  int32_t defense;    /* queried defense, or link_marker when that is > 0 (:2099, :2131-2133) */
-} ygo_card; /* 20 bytes */
+  /* low 16 bits of the queried attack / defense: float_transform (:704-710) takes x % 65536 and
+   * keeps two bytes, so nothing above bit 15 can reach an observation */
+  uint16_t attack;    /* queried attack (:2098) */
+  uint16_t defense;   /* queried defense, or link_marker when that is > 0 (:2099, :2131-2133) */
+} ygo_card; /* 16 bytes */
 
 /* One option after the host has applied the per-message grammar of _set_obs_action
  * (:1674-1765): the nine spec-independent feature bytes (columns 2*mms .. 2*mms+8) and the
@@ -97,10 +99,9 @@ typedef struct {
   uint8_t feats[9];  /* msg, act(+offset), yes/no, phase, cancel/finish, position, option, place, attrib */
   uint8_t n_specs;   /* 0..max_multi_select */
   uint8_t pad[2];
-  /* key = opponent | (location&0x7f)<<8 | sequence<<16 | (has_suffix ? pos+1 : 0)<<24,
+} ygo_option_head; /* 12 bytes, followed by uint32_t spec_key[max_multi_select]:
+   * key = opponent | (location&0x7f)<<8 | sequence<<16 | (has_suffix ? pos+1 : 0)<<24,
    * "opponent" relative to to_play (a leading 'o', :358-365); suffix = overlay letter (:352-354) */
-  uint32_t spec_key[EP_YGO_MAX_SPECS];
-} ygo_option; /* 44 bytes */
 
 /* ---- static card table (replaces init_module's cards_/card_ids_, ygopro.h:1030-1064) -- */
 typedef struct {

@@ -36,7 +36,7 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
   listed = loc[:, 0, :].sum(1) + loc[:, 1, 2:6].sum(1) + np.where(revealed_any, loc[:, 1, 1], 0)
   n_opt = np.minimum(hdr[:, 3].astype(np.int64), cfg.max_options)
   nf = 9 + 2 * cfg.max_multi_select
-  read_b = 64 + cfg.n_history_actions * nf + listed * 20 + n_opt * 44
+  read_b = 64 + cfg.n_history_actions * nf + listed * 16 + n_opt * (12 + 4 * cfg.max_multi_select)
   read_b = np.where(hdr[:, 3] == 0, 64, read_b)
   write_b = 2 * cfg.max_cards * 39 + 8 + cfg.max_options * nf + cfg.n_history_actions * nf + 4 * 4 + (4 + 4 + 4 + 1 + 4 + 4 + 4 + 1) \
       + cfg.max_options * cfg.max_multi_select * 2
