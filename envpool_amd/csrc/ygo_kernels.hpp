@@ -260,11 +260,9 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
     KArgs ka = late_args();
-    uint8_t* g_cards = ka->out.cards + env * (int64_t)(R * 39);
     uint8_t* g_actions = ka->out.actions + env * (int64_t)(a.max_options * nf);
     uint8_t* g_hact = ka->out.h_actions + env * (int64_t)hist_bytes;
     uint8_t* g_hcids = reinterpret_cast<uint8_t*>(ka->out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
-    if (!(YGO_SKIP & 16)) wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
     wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
     wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
     wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
@@ -589,6 +587,12 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       }
     }
     wave_fence();
+    // obs:cards_ is complete: its 5.7 KB leave the CU now, under the option phase (which only
+    // reads the image), instead of at the very end of the wave's life
+    if (!(YGO_SKIP & 16)) {
+      uint8_t* g_cards = late_args()->out.cards + e * (int64_t)(R * 39);
+      wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
+    }
     YGO_STAMP(4);
     // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
     // one of them, the reference the LAST one; detect it and take the exact scan instead
