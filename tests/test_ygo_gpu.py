@@ -47,6 +47,10 @@ def test_known_answers_on_gpu():
   (20000, 15, {}), (20000, 25, {}), (20000, 35, {}), (20000, 45, {}),  # 10^5 randomised records in all
   (513, 6, dict(max_cards=60, max_options=12, n_history_actions=8, max_multi_select=3)),
   (300, 7, dict(max_cards=100, max_options=24, n_history_actions=20, max_multi_select=8)),
+  # history ring longer than 512 bytes (tail path), every limit at its maximum
+  (200, 8, dict(max_cards=127, max_options=64, n_history_actions=40, max_multi_select=8)),
+  # a record larger than the card image (the landing area decides the LDS carve), one spec per option
+  (257, 9, dict(max_cards=40, max_options=32, n_history_actions=30, max_multi_select=1)),
 ])
 def test_synthetic_parity(n, seed, kw):
   from oracle import ygo_oracle
