@@ -164,3 +164,42 @@ def test_python_front_end_and_action_mask():
   has_opts = out["obs:global_"][ok][:, 7] == 0
   assert (acts[has_opts][:, 0, 10] != 0).all()  # a real option always carries its msg id (col 2*mms)
   enc.close()
+
+
+def test_full_size_batch_properties():
+  """65 536 records in one launch (the bench size): (i) the first 4096 match the oracle, (ii) the
+  result does not depend on where in the batch a record sits (a permuted batch gives the permuted
+  result), (iii) a checksum of the whole batch equals the sum of the checksums of 1024-record
+  launches over the same records."""
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  n_gen, n = 4096, 65536
+  cfg = capi_ygo.default_config(max_batch=n, ring_depth=1)
+  table = ygo_synth.make_table(1000, seed=11)
+  sb = ygo_synth.SynthBatch(cfg, table, n_gen, seed=11)
+  want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n_gen)
+  recs, est = capi_ygo.emit_records(cfg, sb.raw, n_gen)
+  ok = np.nonzero((status == 0) & (est == 0))[0]
+  rng = np.random.default_rng(11)
+  pick = rng.integers(0, n_gen, size=n)
+  pick[:n_gen] = np.arange(n_gen)
+  big = np.ascontiguousarray(recs[pick])
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  got = enc.featurize(big, allow=(capi.EP_ERR_ACTION_CHECK,))
+  _compare([g[:n_gen] for g in got], want, ok, "full-size head")
+  perm = rng.permutation(n)
+  got_p = enc.featurize(np.ascontiguousarray(big[perm]), allow=(capi.EP_ERR_ACTION_CHECK,))
+  for k, (a, b) in enumerate(zip(got, got_p)):
+    assert np.array_equal(a[perm], b), capi_ygo.YGO_STATE_KEYS[k]
+  enc.close()
+
+  def checksum(arrs):
+    return [int(a.astype(np.uint64).sum()) if a.dtype != np.float32 else int(a.view(np.uint32).astype(np.uint64).sum()) for a in arrs]
+
+  small = capi_ygo.YgoEncoderC(capi_ygo.default_config(max_batch=1024), table, len(table))
+  acc = None
+  for i in range(0, n, 1024):
+    part = checksum(small.featurize(big[i:i + 1024], allow=(capi.EP_ERR_ACTION_CHECK,)))
+    acc = part if acc is None else [x + y for x, y in zip(acc, part)]
+  small.close()
+  assert acc == checksum(got)
