@@ -103,6 +103,12 @@ def test_rollout_matches_stepwise_oracle(n, T, depth):
   _rollout_case(n, T, seed=1, ring_depth=depth)
 
 
+def test_rollout_at_bench_size():
+  """BASELINE config 2 as bench.py runs it: 65 536 envs, seed 42, T = 128 steps per launch, ring
+  depth 256 - every step of the fused loop against the oracle, plus the episode statistics."""
+  _rollout_case(65536, 128, seed=42, ring_depth=256, rounds=1)
+
+
 def test_rollout_reports_action_check():
   """list_action lanes that differ abort the reference (dummy_envpool.h:189-192); here the
   batch comes back and recv reports EP_ERR_ACTION_CHECK."""
