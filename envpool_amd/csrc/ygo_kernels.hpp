@@ -328,30 +328,55 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     int n_cards = 0, n0 = 0, shift1 = 0, fit_end0 = 0, fit_end1 = 0, hand1_lo = 0, hand1_hi = 0;
     int ph_row[3] = {0, 0, 0}, ph_cnt[3] = {0, 0, 0};
     if (!no_options) {
+      bool over = false;
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         int row = pi * a.max_cards;
-        if (pi == 1) { n0 = n_cards; fit_end1 = n_cards; }
+        if (pi == 1) n0 = n_cards;
 #pragma unroll
         for (int li = 0; li < 7; ++li) {
           const int s = pi * 7 + li;
           const int cnt = (int)((w[12 + (s >> 2)] >> (8 * (s & 3))) & 0xff);
           bool hidden = (li == 0 || li == 1 || li == 6);
           if (li == 1 && revealed_any) hidden = false;  // :1522-1525
-          const bool count_only = pi == 1 && hidden;
-          const bool fits = row + cnt <= (pi + 1) * a.max_cards;
-          if (!fits) bad_u = true;
-          if (count_only) {
+          if (pi == 1 && hidden) {
             const int ph = li == 0 ? 0 : (li == 1 ? 1 : 2);
             ph_row[ph] = row;
-            ph_cnt[ph] = fits ? cnt : 0;
+            ph_cnt[ph] = cnt;
           } else {
             if (pi == 1 && li == 1) { hand1_lo = n_cards; hand1_hi = n_cards + cnt; }
             if (pi == 1 && li == 2) shift1 = row - n_cards;  // the same for every listed pi=1 segment
-            if (fits) { if (pi == 0) fit_end0 = n_cards + cnt; else fit_end1 = n_cards + cnt; }
             n_cards += cnt;
           }
           row += cnt;
+        }
+        if (row > (pi + 1) * a.max_cards) over = true;
+      }
+      fit_end0 = n0;
+      fit_end1 = n_cards;
+      if (over) {  // some player has more rows than max_cards: find where each stops fitting
+        bad_u = true;
+        int nc = 0;
+        fit_end0 = 0;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          int row = pi * a.max_cards;
+          if (pi == 1) fit_end1 = nc;
+#pragma unroll
+          for (int li = 0; li < 7; ++li) {
+            const int s = pi * 7 + li;
+            const int cnt = (int)((w[12 + (s >> 2)] >> (8 * (s & 3))) & 0xff);
+            bool hidden = (li == 0 || li == 1 || li == 6);
+            if (li == 1 && revealed_any) hidden = false;
+            const bool fits = row + cnt <= (pi + 1) * a.max_cards;
+            if (pi == 1 && hidden) {
+              if (!fits) ph_cnt[li == 0 ? 0 : (li == 1 ? 1 : 2)] = 0;
+            } else {
+              if (fits) { if (pi == 0) fit_end0 = nc + cnt; else fit_end1 = nc + cnt; }
+              nc += cnt;
+            }
+            row += cnt;
+          }
         }
       }
     }
