@@ -91,6 +91,33 @@ def test_throw_conditions_are_reported():
   assert enc.last_status == 0  # the flag does not stick
 
 
+def test_more_rows_than_max_cards_is_flagged_and_neighbours_stay_exact():
+  """The reference has no bound on rows per player (it would overrun obs:cards_); the oracle
+  reports a throw, the kernel flags the batch and leaves the offending location out, and the other
+  records of the batch are untouched by it."""
+  from oracle import ygo_oracle
+  cfg = capi_ygo.default_config(max_batch=16, max_cards=4)
+  table = ygo_build.make_table(GOLD["table"])
+  code = GOLD["table"][0]["code"]
+  ok_state = {"options": ["y"], "msg": 13, "field": {"p0": {"grave": [{"code": code, "seq": i} for i in range(3)]}}}
+  over_own = {"options": ["y"], "msg": 13, "field": {"p0": {"hand": [{"code": code, "seq": 0}],
+                                                            "grave": [{"code": code, "seq": i} for i in range(5)]}}}
+  over_opp = {"options": ["y"], "msg": 13, "field": {"p1": {"deck": [{"code": code, "seq": i} for i in range(6)]}}}
+  arr, keep = ygo_build.batch_of([ok_state, over_own, ok_state, over_opp, ok_state], n_hist=16, nf=19)
+  want, status = ygo_oracle.write_batch(cfg, table, arr, 5)
+  assert status.tolist() == [0, 6, 0, 6, 0]
+  recs, est = capi_ygo.emit_records(cfg, arr, 5)
+  assert (est == 0).all()
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  got = enc.featurize(recs, allow=(capi.EP_ERR_ACTION_CHECK,))
+  assert enc.last_status == capi.EP_ERR_ACTION_CHECK
+  _compare(got, want, np.array([0, 2, 4]), "neighbours of overflowing records")
+  cards = got[8]
+  assert cards[1][0].any() and not cards[1][1:4].any()   # own hand row written, the 5-card grave left out
+  assert not cards[3][4:].any()                          # the 6-row hidden deck left out
+  enc.close()
+
+
 def test_submit_collect_pipeline_and_device_records():
   """Several batches in flight (pinned staging + side-stream copy), results in FIFO order;
   device-resident records give the same bytes."""
