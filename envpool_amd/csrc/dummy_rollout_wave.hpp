@@ -219,10 +219,30 @@ __device__ __forceinline__ void vm_wait() {
 // One LDS-DMA instruction: every lane copies BYTES from its `gsrc` to lds_base + lane*BYTES.
 // M0 carries the wave-uniform LDS base and is compiler-reserved, so it is saved and restored
 // inside the statement (cdna_hip_programming.md §5.7).
+// Non-temporal policy on the once-read action rows (LDS-DMA loads) and on the once-written
+// StateBuffer rows: measured 188 -> 179 us per 128-step launch at 65 536 envs. The build flags
+// EP_ROLLOUT_NO_NT_LOADS / EP_ROLLOUT_NO_NT_STORES switch either half back to the default policy.
+#ifndef EP_ROLLOUT_NO_NT_LOADS
+#define EP_NT_SUFFIX " nt"
+#else
+#define EP_NT_SUFFIX ""
+#endif
+template <typename V>
+__device__ __forceinline__ void ring_store(V* dst, V v) {
+#ifndef EP_ROLLOUT_NO_NT_STORES
+  static_assert(sizeof(V) == 16, "16-byte ring stores only");
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 raw;
+  __builtin_memcpy(&raw, &v, 16);
+  __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst));
+#else
+  *dst = v;
+#endif
+}
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
   uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" EP_NT_SUFFIX "\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
       : "memory");
@@ -230,7 +250,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
 __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_base) {
   uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" EP_NT_SUFFIX "\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
       : "memory");
@@ -320,8 +340,8 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = *reinterpret_cast<const int2*>(lds + lm.rsrc[c]);
     lds_fence_wave();
-    *reinterpret_cast<uint4*>(sb + lm.dst1) = s1;
-    if (lane < 60) *reinterpret_cast<uint4*>(sb + lm.dst2) = s2;
+    ring_store(reinterpret_cast<uint4*>(sb + lm.dst1), s1);
+    if (lane < 60) ring_store(reinterpret_cast<uint4*>(sb + lm.dst2), s2);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       int4 v;
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
       v.y = lm.rkind[c] == 1u ? p[c].y : 0;
       v.z = lm.rkind[c] == 2u ? p[c].x : 0;
       v.w = lm.rkind[c] == 2u ? p[c].y : 0;
-      if (c < 2 || lane < 32) *reinterpret_cast<int4*>(sb + lm.rdst[c]) = v;
+      if (c < 2 || lane < 32) ring_store(reinterpret_cast<int4*>(sb + lm.rdst[c]), v);
     }
     slot = (slot + 1 == a.ring.depth) ? 0 : slot + 1;
   };
