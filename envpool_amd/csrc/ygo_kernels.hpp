@@ -181,10 +181,15 @@ __device__ __forceinline__ void wave_zero16(unsigned char* lds, int lo, int byte
 // compiler-reserved, so it is saved and restored inside the statement
 // (cdna_hip_programming.md section 5.7). The compiler does not see these loads: the waits for
 // them are the explicit vm_wait below.
+#ifdef YGO_NT_LOADS
+#define YGO_NT_LOAD " nt"
+#else
+#define YGO_NT_LOAD ""
+#endif
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_base) {
   uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" YGO_NT_LOAD "\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
       : "memory");
@@ -204,7 +209,17 @@ __device__ __forceinline__ void wave_flush(uint8_t* g, const unsigned char* lds,
     const int nvec = (bytes - head) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(lds + lo + head);
     uint4* dst = reinterpret_cast<uint4*>(g + head);
+#ifndef YGO_NO_NT_STORES
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int q = lane; q < nvec; q += 64) {  // written once, never re-read by this kernel: non-temporal
+      const uint4 v = src[q];
+      u32x4 raw;
+      __builtin_memcpy(&raw, &v, 16);
+      __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst + q));
+    }
+#else
     for (int q = lane; q < nvec; q += 64) dst[q] = src[q];
+#endif
     const int done = head + (nvec << 4);
     if (lane < bytes - done) g[done + lane] = lds[lo + done + lane];
   } else {
