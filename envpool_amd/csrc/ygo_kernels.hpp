@@ -60,8 +60,8 @@ __host__ __device__ inline int option_bytes(int mms) { return (int)sizeof(ygo_op
 // per-wave LDS arena (byte offsets inside it, all 16-byte aligned). Each image region has 16
 // spare bytes so that the image can start at its destination's address modulo 16.
 struct Carve {
-  int cards, actions, hact, global, hcids, spec, rowkey, stage, wave_stride, total, spec_stride, rowkey_stride;
-  int zero_bytes;                               // [cards, rowkey) starts every env as zeros
+  int cards, actions, hact, global, hcids, spec, stage, wave_stride, total, spec_stride;
+  int zero_bytes;                               // [cards, spec end) starts every env as zeros
   int off_hist, off_cards, off_opts, rec_bytes; // record layout (include/envpool_amd_ygo.h)
   int stage_bytes;                              // rec_bytes rounded up to whole 1 KiB LDS-DMA instructions
 };
@@ -85,8 +85,6 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.spec_stride = spec_table_bytes(max_cards);
   c.spec = o;    o += c.spec_stride;
   c.zero_bytes = o;
-  c.rowkey_stride = al16(R * 4 + R);  // key of listed card k (u32), then its row (u8)
-  c.rowkey = o;  o += c.rowkey_stride;
   c.stage = c.cards;  // the record lands (LDS-DMA) where the card image is built afterwards
 #ifdef YGO_LDS_PAD
   o += YGO_LDS_PAD;  // diagnostic builds: lower the occupancy to see how throughput follows it
@@ -256,8 +254,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
 
   const int arena = wave * cv.wave_stride;
   uint8_t* const my_global = lds + arena + cv.global;
-  uint32_t* const my_rowkey = reinterpret_cast<uint32_t*>(lds + arena + cv.rowkey);
-  uint8_t* const my_krow = reinterpret_cast<uint8_t*>(my_rowkey + R);
   uint8_t* const my_spec = lds + arena + cv.spec;
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
@@ -556,7 +552,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // Every listed row also enters the env's direct-mapped spec table (the reference's per-step
     // spec2index hash map, :1549). ----
     int ti_of[4];
-    uint32_t row1_of[4];
+    uint32_t row1_of[4], key_of[4];  // spec-table slot, 1-based row and spec key of the lane's cards
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       // one card at a time, unpacked here and no earlier
@@ -564,6 +560,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       const int k = lane + 64 * it;
       ti_of[it] = -1;
       row1_of[it] = 0;
+      key_of[it] = 0xffffffffu;
       if (k < n_listed && !(YGO_SKIP & 1)) {
         const uint32_t pi = k >= n0 ? 1u : 0u;
         uint32_t key = 0xffffffffu;
@@ -619,11 +616,10 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
           const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
           if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
-          my_krow[k] = (uint8_t)(r + 1);  // row of listed card k
           ti_of[it] = ti;
           row1_of[it] = (uint32_t)(r + 1) & 0xff;
+          key_of[it] = key;
         }
-        my_rowkey[k] = key;
       }
     }
     wave_fence();
@@ -644,31 +640,46 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
     for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) asm volatile("" : "+v"(mw[d]));
-    if (lane < n_opt && !(YGO_SKIP & 8)) {
+    if (!(YGO_SKIP & 8)) {
       uint8_t* arow = my_actions + lane * nf;
-      const int ns = min((int)((mw[2] >> 8) & 0xff), a.mms);
+      const int ns = lane < n_opt ? min((int)((mw[2] >> 8) & 0xff), a.mms) : 0;
       bool open = true;
 #pragma unroll
       for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
-        if (j < ns) {
+        if (__any(j < ns)) {  // wave-uniform: the exact scan below is a whole-wave affair
+          const bool act = j < ns;
           const uint32_t key = mw[3 + j];
           const int ti = spec_slot(key, a.max_cards);
+          const bool fast = act & (ti >= 0) & !dup;
           int idx = 0;
-          if (ti >= 0 && !dup) {
-            idx = my_spec[ti];
-          } else {
-            for (int k = 0; k < n_listed; ++k)
-              if (my_rowkey[k] == key) idx = max(idx, (int)my_krow[k]);  // last row wins (:1549)
+          if (fast) idx = my_spec[ti];
+          // A key outside the direct-mapped table, or an env with two rows under one spec: the
+          // exact search, last row wins (:1549). Rare; done by the whole wave for one option at a
+          // time - every lane compares the key with the cards it owns, then a wave-wide maximum.
+          uint64_t need = __ballot(act & !fast);
+          while (need) {
+            const int src = __ffsll((unsigned long long)need) - 1;
+            need &= need - 1;
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
+            int best = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+              if (key_of[it] == want) best = max(best, (int)row1_of[it]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+            if (lane == src) idx = best;
           }
-          badv |= idx == 0 ? 1u : 0u;  // spec2index.at(spec) throws
-          arow[2 * j] = (uint8_t)(idx >> 8);
-          arow[2 * j + 1] = (uint8_t)(idx & 0xff);
-          // read back from the images, literally: low byte only (Q7), stop at the first zero
-          const int spec_index = idx & 0xff;
-          if (spec_index == 0) open = false;
-          if (open) {
-            const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
-            my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
+          if (act) {
+            badv |= idx == 0 ? 1u : 0u;  // spec2index.at(spec) throws
+            arow[2 * j] = (uint8_t)(idx >> 8);
+            arow[2 * j + 1] = (uint8_t)(idx & 0xff);
+            // read back from the images, literally: low byte only (Q7), stop at the first zero
+            const int spec_index = idx & 0xff;
+            if (spec_index == 0) open = false;
+            if (open) {
+              const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
+              my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
+            }
           }
         }
       }

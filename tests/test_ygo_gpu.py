@@ -118,6 +118,38 @@ def test_more_rows_than_max_cards_is_flagged_and_neighbours_stay_exact():
   enc.close()
 
 
+def test_exact_spec_search_paths():
+  """Specs the direct-mapped table cannot hold (sequence >= max_cards) and envs with two rows under
+  one spec (never in a consistent duel; the reference's map keeps the LAST row) go through the
+  wave-cooperative exact search."""
+  from oracle import ygo_oracle
+  cfg = capi_ygo.default_config(max_batch=16)
+  table = ygo_build.make_table(GOLD["table"])
+  codes = [c["code"] for c in GOLD["table"]]
+  dup = {"options": ["s m3", "t m3", "c g1"], "msg": 11,
+         "field": {"p0": {"mzone": [{"code": codes[0], "seq": 2}, {"code": codes[1], "seq": 2}, {"code": codes[2], "seq": 0}],
+                          "grave": [{"code": codes[1], "seq": 0}]}}}
+  far = {"options": ["g201", "g3 g201"], "msg": 15,
+         "field": {"p0": {"grave": [{"code": codes[0], "seq": 2}, {"code": codes[1], "seq": 200}]},
+                   "p1": {"grave": [{"code": codes[2], "seq": 200}]}}}
+  both = {"options": ["os1", "os1 og150"], "msg": 15,
+          "field": {"p1": {"szone": [{"code": codes[0], "seq": 0}, {"code": codes[1], "seq": 0}],
+                           "grave": [{"code": codes[2], "seq": 149}]}}}
+  plain = GOLD["cases"][0]["state"]
+  arr, keep = ygo_build.batch_of([plain, dup, far, both, plain])
+  want, status = ygo_oracle.write_batch(cfg, table, arr, 5)
+  assert status.tolist() == [0] * 5
+  recs, est = capi_ygo.emit_records(cfg, arr, 5)
+  assert (est == 0).all()
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  got = enc.featurize(recs)
+  _compare(got, want, np.arange(5), "exact search")
+  acts = got[10]
+  assert acts[1][0][1] == 2 and acts[1][1][1] == 2  # "m3" -> the LAST of the two rows (row index 2)
+  assert acts[2][0][1] == 2 and acts[2][1][:4].tolist() == [0, 1, 0, 2]
+  enc.close()
+
+
 def test_submit_collect_pipeline_and_device_records():
   """Several batches in flight (pinned staging + side-stream copy), results in FIFO order;
   device-resident records give the same bytes."""
