@@ -32,10 +32,10 @@ Layout make_layout(const ep_ygo_config& c) {
   Layout l;
   l.nf = 9 + 2 * c.max_multi_select;
   l.off_hist = 64;
-  l.off_cards = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
-  l.off_opts = l.off_cards + 2 * c.max_cards * (int)sizeof(ygo_card);
-  l.off_opts = (l.off_opts + 15) & ~15;
-  l.stride = (int64_t)align_up((size_t)l.off_opts + (size_t)c.max_options * ygk::option_bytes(c.max_multi_select));
+  l.off_opts = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
+  l.off_cards = l.off_opts + c.max_options * ygk::option_bytes(c.max_multi_select);
+  l.off_cards = (l.off_cards + 15) & ~15;
+  l.stride = (int64_t)align_up((size_t)l.off_cards + (size_t)2 * c.max_cards * sizeof(ygo_card));
   return l;
 }
 

@@ -72,9 +72,10 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   const int nf = 9 + 2 * mms, R = 2 * max_cards;
   Carve c;
   c.off_hist = 64;
-  c.off_cards = c.off_hist + al16(n_hist * nf);
-  c.off_opts = al16(c.off_cards + R * (int)sizeof(ygo_card));
-  c.rec_bytes = al16(c.off_opts + max_options * option_bytes(mms));
+  // the card array comes LAST: only its used prefix is fetched
+  c.off_opts = c.off_hist + al16(n_hist * nf);
+  c.off_cards = al16(c.off_opts + max_options * option_bytes(mms));
+  c.rec_bytes = al16(c.off_cards + R * (int)sizeof(ygo_card));
   c.stage_bytes = (c.rec_bytes + 1023) & ~1023;
   int o = 0;
   c.cards = o;   o += max(al16(R * 39) + 16, c.stage_bytes);  // doubles as the record's landing area
@@ -257,16 +258,19 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   uint8_t* const my_spec = lds + arena + cv.spec;
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
-  const int n_chunks = cv.rec_bytes >> 4, n_dma = cv.stage_bytes >> 10;
-  auto fetch = [&](int64_t env) {
-    const uint8_t* g = a.records + env * a.stride;
-    lds_drain();  // every earlier LDS read of the stage has returned
-    for (int c = 0; c < n_dma; ++c) {
-      const int chunk = min(lane + 64 * c, n_chunks - 1);  // the pad lanes re-read the last chunk
-      dma16(g + (int64_t)chunk * 16, stage_lds + 1024u * (uint32_t)c);
+  // The record is fetched in two parts: everything up to the card array plus the first 64 cards
+  // at once (whole 1 KiB DMA instructions), the rest of the LISTED cards once the header has told
+  // how many there are - the unused tail of the card array never leaves HBM. `last` is the last
+  // 16-byte piece wanted: lanes past it re-read it (same cache line, no extra traffic).
+  const uint8_t* const rec = a.records + e * a.stride;
+  const int n_dma_first = min((cv.off_cards + 64 * (int)sizeof(ygo_card) + 1023) >> 10, cv.stage_bytes >> 10);
+  auto fetch = [&](int c_lo, int c_hi, int last) {
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int piece = min(lane + 64 * c, last);
+      dma16(rec + (int64_t)piece * 16, stage_lds + 1024u * (uint32_t)c);
     }
   };
-  fetch(e);
+  fetch(0, n_dma_first, (cv.rec_bytes >> 4) - 1);
 
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
@@ -398,12 +402,20 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // until the code that needs a field: unpacked early they cost 60 more VGPRs.
     uint32_t cw[4][4];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack,defense
     uint32_t mw[3 + EP_YGO_MAX_SPECS];  // option: feats[0..8], n_specs, pad | spec_key[max_multi_select]
-    // (read unconditionally, index clamped into the array: a lane beyond the listed cards / the
-    // options holds words it never uses - the emitter zero-fills the unused tail, so those lanes
-    // all probe the hash slot of code 0)
+    // (read unconditionally, index clamped: a lane beyond the listed cards / the options holds
+    // words it never uses, and its hash probe coalesces with the last listed card's)
+    {  // second part of the record: listed cards beyond what the first fetch covered (if any)
+      const int need_pieces = (cv.off_cards >> 4) + n_listed;
+      if (need_pieces > n_dma_first * 64) {
+        fetch(n_dma_first, (need_pieces + 63) >> 6, need_pieces - 1);
+        vm_wait<0>();
+        wave_fence();
+      }
+    }
+    const int last_card = max(n_listed, 1) - 1;  // lanes without a card re-read the last listed one
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const uint4 c4 = reinterpret_cast<const uint4*>(stage + cv.off_cards)[min(lane + 64 * it, R - 1)];  // one 16-byte read
+      const uint4 c4 = reinterpret_cast<const uint4*>(stage + cv.off_cards)[min(lane + 64 * it, last_card)];  // one 16-byte read
       cw[it][0] = c4.x; cw[it][1] = c4.y; cw[it][2] = c4.z; cw[it][3] = c4.w;
     }
     {

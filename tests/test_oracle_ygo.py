@@ -99,14 +99,14 @@ def test_emitter_record_fields():
   assert mask == 1  # only "oh1" matters; "g9" is not an opponent-hand spec
   loc = rec[48:62].reshape(2, 7)
   assert loc.tolist() == [[0, 0, 3, 0, 0, 0, 0], [2, 2, 0, 0, 0, 0, 0]]
-  off_cards = 64 + ((16 * 19 + 15) // 16) * 16
+  off_opts = 64 + ((16 * 19 + 15) // 16) * 16
+  off_cards = (off_opts + 16 * (12 + 4 * 5) + 15) // 16 * 16
   cards = np.frombuffer(rec[off_cards:off_cards + 5 * 16].tobytes(), dtype=np.dtype(
     [("code", "<u4"), ("ctrl", "u1"), ("loc", "u1"), ("seq", "u1"), ("pos", "u1"), ("level", "u1"), ("rank", "u1"),
      ("link", "u1"), ("mat", "u1"), ("atk", "<u2"), ("def", "<u2")]))
   assert cards["code"].tolist() == [46986414, 55144522, 10000, 55144522, 89631139]
   assert cards["loc"].tolist() == [0x84, 0x84, 0x04, 0x02, 0x02] and cards["mat"].tolist() == [1, 1, 0, 0, 0]
   assert cards["pos"].tolist()[:2] == [0, 1] and cards["rank"][2] == 4 and cards["atk"][2] == 0xfffe  # low 16 bits of -2
-  off_opts = (off_cards + 150 * 16 + 15) // 16 * 16
   opt0 = rec[off_opts:off_opts + 12 + 4 * 5]
   assert opt0[0] == 3 and opt0[9] == 2  # msg id, n_specs
   keys = np.frombuffer(opt0[12:20].tobytes(), "<u4").tolist()
@@ -125,8 +125,7 @@ def test_emitter_option_grammar(msg, opt, feat_col, val):
   arr, keep = ygo_build.batch_of([{"msg": msg, "options": [opt]}])
   recs, status = capi_ygo.emit_records(cfg, arr, 1)
   assert status[0] == 0
-  off_cards = 64 + 304
-  off_opts = (off_cards + 150 * 16 + 15) // 16 * 16
+  off_opts = 64 + 304
   feats = recs[0][off_opts:off_opts + 9].tolist()
   want = [0] * 9
   want[0] = [11, 16, 15, 20, 19, 12, 13, 10, 26, 14, 18, 23, 24, 141].index(msg) + 1
