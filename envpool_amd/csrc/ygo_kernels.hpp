@@ -436,8 +436,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
     uint4 tq[4], tq2[4];  // HashEntry: code | type | card_id, level, attr_id | race_id (both candidate slots)
     const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    auto probe = [&](int it) {
       if (!(YGO_SKIP & (32 | 64))) {
         tq[it] = table_q[slot_a(cw[it][0], a.table_mask)];
         tq2[it] = table_q[slot_b(cw[it][0], a.table_mul_b, a.table_mask)];
@@ -445,6 +444,15 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
         tq[it] = tq2[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
       if (YGO_SKIP & 32) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
+    };
+    probe(0);
+    if (n_listed > 64) {  // wave-uniform: most duel states list fewer than 64 cards
+      probe(1);
+      probe(2);
+      probe(3);
+    } else {
+#pragma unroll
+      for (int it = 1; it < 4; ++it) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
     }
     // rings longer than 512 bytes: the tail goes from the stage to the image now
     if (hist_bytes > 512 && !no_options) {
