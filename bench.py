@@ -82,8 +82,8 @@ def main():
 
   L = capi.lib()
   N, T = NUM_ENVS, T_FUSED
-  K = max(T, (args.steps + T - 1) // T * T)
-  W = (args.warmup + T - 1) // T * T
+  K = max(1, args.steps)   # timed lockstep steps: exactly what was asked for
+  W = max(0, args.warmup)
   pool = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=dev_index, env_id_offset=rank * N,
                          ring_depth=2 * T)
   h = pool.handle
@@ -111,8 +111,8 @@ def main():
     if rc != 0:
       raise RuntimeError(L.ep_last_error().decode())
 
-  def recv_T():
-    check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, T, batches))
+  def recv_n(n):
+    check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, n, batches))
 
   def exchange_stats():
     if world > 1:
@@ -131,13 +131,14 @@ def main():
         dist.all_gather_into_tensor(g_len, st_len)
 
   def run_fused(n_steps):
-    rounds = n_steps // T
-    check(L.ep_pool_rollout(h, T, 5, ptrs, dims, strides))
-    for _ in range(rounds - 1):
-      check(L.ep_pool_rollout(h, T, 5, ptrs, dims, strides))  # next rollout queued ...
-      recv_T()                                                # ... while this one is received
+    # whole launches of T steps, then one shorter launch for the remainder (n_steps % T)
+    chunks = [T] * (n_steps // T) + ([n_steps % T] if n_steps % T else [])
+    check(L.ep_pool_rollout(h, chunks[0], 5, ptrs, dims, strides))
+    for i in range(1, len(chunks)):
+      check(L.ep_pool_rollout(h, chunks[i], 5, ptrs, dims, strides))  # next rollout queued ...
+      recv_n(chunks[i - 1])                                           # ... while this one is received
       exchange_stats()
-    recv_T()
+    recv_n(chunks[-1])
     exchange_stats()
     check(L.ep_pool_sync(h))
 
@@ -163,12 +164,14 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-  kern_us = tot.value / max(1, cnt.value)  # average rollout-kernel duration (HIP events)
+  n_launch = max(1, cnt.value)
+  kern_total_us = tot.value
+  kern_us = kern_total_us / n_launch  # average rollout-kernel duration (HIP events)
 
   # one-launch-per-step mode, measured on rank 0's pool the same way (reported, not `value`)
   per_step = None
   if True:
-    ks = min(K, 512)
+    ks = max(16, min(K, 512))
     la1 = la[0].contiguous()
     p1 = (C.c_void_p * 5)(env_id.data_ptr(), env_id.data_ptr(), la1.data_ptr(), unused.data_ptr(), unused.data_ptr())
     torch.cuda.synchronize()
@@ -293,10 +296,12 @@ def main():
     if os.path.exists(pmc_path):
       try:
         # measured with rocprofv3 --pmc at T=64 (profiles/): bytes scale with the steps per launch
-        traffic = json.load(open(pmc_path))["rollout_hbm_bytes_per_env_step"] * N * T
+        traffic = json.load(open(pmc_path))["rollout_hbm_bytes_per_env_step"] * N * K / n_launch
       except Exception:
         traffic = None
-    alg_launch = N * (T * ALG_ROLLOUT_PER_ENV_STEP + ALG_ROLLOUT_PER_ENV_LAUNCH)
+    # K steps in n_launch launches (T steps each, the last one possibly shorter): per-launch figures
+    # are averages over the timed region
+    alg_launch = N * (K * ALG_ROLLOUT_PER_ENV_STEP + n_launch * ALG_ROLLOUT_PER_ENV_LAUNCH) / n_launch
     achieved = alg_launch / (kern_us * 1e-6) / 1e9
     line = {
       "metric": "env-steps/sec (whole node) Dummy-v0", "value": world * N * K / elapsed, "unit": "env-steps/s",
@@ -312,7 +317,7 @@ def main():
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "kernel": "dummy_rollout_dma<4>", "kernel_us": kern_us,
+        "kernel": "dummy_rollout_dma<4>", "kernel_us": kern_us, "launches": n_launch,
         "alg_bytes_per_launch": alg_launch,
       },
       "per_step_launch": per_step,
