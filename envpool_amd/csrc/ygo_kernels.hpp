@@ -136,14 +136,14 @@ __host__ __device__ inline uint32_t type_bit(int j) {  // ascending TYPE_* keys 
 // exact linear scan is used): plain specs by (opponent, location, sequence < max_cards), overlay
 // specs by (opponent, monster zone < 8, letter < 8).
 __device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
+  // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
   const uint32_t opp = key & 0xff, loc7 = (key >> 8) & 0xff, seq = (key >> 16) & 0xff, suf = key >> 24;
-  if (opp > 1 || loc7 == 0 || (loc7 & (loc7 - 1)) != 0 || loc7 > 0x40) return -1;
-  if (suf == 0) {
-    if (seq >= (uint32_t)max_cards) return -1;
-    return (int)((opp * 7 + (uint32_t)__ffs(loc7) - 1) * (uint32_t)max_cards + seq);
-  }
-  if (loc7 != 0x04 || seq >= 8 || suf > 8) return -1;
-  return 14 * max_cards + (int)((opp * 8 + seq) * 8 + (suf - 1));
+  const bool loc_ok = (opp <= 1) & (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
+  const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)max_cards);
+  const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
+  const int ti_plain = (int)((opp * 7 + (uint32_t)__ffs(loc7) - 1) * (uint32_t)max_cards + seq);
+  const int ti_over = 14 * max_cards + (int)((opp * 8 + seq) * 8 + (suf - 1));
+  return plain_ok ? ti_plain : (over_ok ? ti_over : -1);
 }
 
 #ifndef YGO_SKIP
