@@ -23,7 +23,7 @@
 namespace ygk {
 
 #ifndef YGO_WAVES
-#define YGO_WAVES 2
+#define YGO_WAVES 4
 #endif
 constexpr int kGroup = YGO_WAVES;       // envs (= waves) per workgroup; any value works
 constexpr int kThreads = 64 * kGroup;   // one wave64 per env
