@@ -278,9 +278,9 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     uint8_t* g_actions = ka->out.actions + env * (int64_t)(a.max_options * nf);
     uint8_t* g_hact = ka->out.h_actions + env * (int64_t)hist_bytes;
     uint8_t* g_hcids = reinterpret_cast<uint8_t*>(ka->out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
-    wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
-    wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
-    wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
+    if (!(YGO_SKIP & 1024)) wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
+    if (!(YGO_SKIP & 1024)) wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
+    if (!(YGO_SKIP & 1024)) wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
     if (lane < 8) ka->out.global[env * 8 + lane] = my_global[lane];
   };
 
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
           lds + arena + cv.hcids + (int)(((uint32_t)(uintptr_t)ka->out.h_card_ids + e4 * (uint32_t)(a.max_options * a.mms * 2)) & 14u));
     }
 
-    wave_zero16(lds, arena + cv.actions, cv.zero_bytes - cv.actions, lane);
+    if (!(YGO_SKIP & 512)) wave_zero16(lds, arena + cv.actions, cv.zero_bytes - cv.actions, lane);
     // ---- A ----
     vm_wait<0>();
     wave_fence();
@@ -468,14 +468,14 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     YGO_STAMP(1);
     // ---- D ----
     wave_fence();
-    wave_zero16(lds, arena + cv.cards, cv.actions, lane);
+    if (!(YGO_SKIP & 128)) wave_zero16(lds, arena + cv.cards, cv.actions, lane);
     wave_fence();
 
     // ---- E: hidden opponent locations get placeholder rows {col2 = location id, col4 = 1}
     // (:1526-1532); obs:global_ (:1605-1620) ----
 #pragma unroll
     for (int ph = 0; ph < 3; ++ph)
-      for (int q = lane; q < ph_cnt[ph]; q += 64) {
+      for (int q = lane; q < ph_cnt[ph] && !(YGO_SKIP & 256); q += 64) {
         uint8_t* prow = my_cards + (ph_row[ph] + q) * 39;
         prow[2] = (uint8_t)(ph == 0 ? 1 : (ph == 1 ? 2 : 7));
         prow[4] = 1;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     // ---- C: scalars + Env::Allocate common fields (env.h:196-222). Issued only now: VMEM retires
     // in issue order, so stores in front of the probe wait above would have put their
     // acknowledgement latency into it ----
-    if (lane == 0) {
+    if (lane == 0 && !(YGO_SKIP & 2048)) {
       KArgs ka = late_args();
       const bool done = (w[1] >> 24) != 0;
       const int elapsed = (int)w[3];
