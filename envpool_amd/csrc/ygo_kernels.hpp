@@ -15,6 +15,7 @@
 // per-env direct-mapped table in LDS (the reference's per-step spec2index hash map), and
 // h_card_ids is derived from the image exactly as :1863-1879 reads it back from obs.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -172,7 +173,11 @@ __device__ __forceinline__ void wave_fence() {
 // zero the 16-byte aligned LDS span [lo, lo+bytes) with one wave
 __device__ __forceinline__ void wave_zero16(unsigned char* lds, int lo, int bytes, int lane) {
   const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int q = lane; q < (bytes >> 4); q += 64) reinterpret_cast<uint4*>(lds + lo)[q] = z;
+  uint4* p = reinterpret_cast<uint4*>(lds + lo) + lane;
+  const int nq = bytes >> 4, full = nq >> 6;  // whole-wave iterations need no per-lane bound check
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+  for (int i = 0; i < full; ++i) p[64 * i] = z;
+  if (lane < nq - 64 * full) p[64 * full] = z;
 }
 
 // One LDS-DMA instruction: every lane copies 16 bytes from its `gsrc` to lds_base + lane*16 (1 KiB
@@ -205,23 +210,27 @@ __device__ __forceinline__ void wave_flush(uint8_t* g, const unsigned char* lds,
   if ((((uintptr_t)g ^ (uintptr_t)lo) & 15) == 0) {
     const int head = min((16 - (lo & 15)) & 15, bytes);
     if (lane < head) g[lane] = lds[lo + lane];
-    const int nvec = (bytes - head) >> 4;
-    const uint4* src = reinterpret_cast<const uint4*>(lds + lo + head);
-    uint4* dst = reinterpret_cast<uint4*>(g + head);
-#ifndef YGO_NO_NT_STORES
+    const int nvec = (bytes - head) >> 4, full = nvec >> 6;
+    const unsigned char* src = lds + lo + head;
+    uint8_t* dst = g + head;  // wave-uniform base; the lane part stays a 32-bit offset
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (int q = lane; q < nvec; q += 64) {  // written once, never re-read by this kernel: non-temporal
-      const uint4 v = src[q];
+    auto piece = [&](uint32_t off) {  // written once, never re-read by this kernel: non-temporal
+      const uint4 v = *reinterpret_cast<const uint4*>(src + off);
       u32x4 raw;
       __builtin_memcpy(&raw, &v, 16);
-      __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst + q));
-    }
+#ifndef YGO_NO_NT_STORES
+      __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst + off));
 #else
-    for (int q = lane; q < nvec; q += 64) dst[q] = src[q];
+      *reinterpret_cast<u32x4*>(dst + off) = raw;
 #endif
+    };
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int i = 0; i < full; ++i) piece((uint32_t)(lane + 64 * i) << 4);
+    if (lane < nvec - 64 * full) piece((uint32_t)(lane + 64 * full) << 4);
     const int done = head + (nvec << 4);
     if (lane < bytes - done) g[done + lane] = lds[lo + done + lane];
   } else {
+#pragma unroll 1
     for (int b = lane; b < bytes; b += 64) g[b] = lds[lo + b];
   }
 }
@@ -254,7 +263,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   if (e >= a.n) return;  // wave-uniform; no workgroup barrier anywhere in this kernel
 
   const int arena = wave * cv.wave_stride;
-  uint8_t* const my_global = lds + arena + cv.global;
   uint8_t* const my_spec = lds + arena + cv.spec;
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
@@ -275,13 +283,37 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
     KArgs ka = late_args();
-    uint8_t* g_actions = ka->out.actions + env * (int64_t)(a.max_options * nf);
+    const int act_bytes = a.max_options * nf, cid_bytes = a.max_options * a.mms * 2;
+    uint8_t* g_actions = ka->out.actions + env * (int64_t)act_bytes;
     uint8_t* g_hact = ka->out.h_actions + env * (int64_t)hist_bytes;
-    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(ka->out.h_card_ids + env * (int64_t)(a.max_options * a.mms));
-    if (!(YGO_SKIP & 1024)) wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), a.max_options * nf, lane);
-    if (!(YGO_SKIP & 1024)) wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
-    if (!(YGO_SKIP & 1024)) wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), a.max_options * a.mms * 2, lane);
-    if (lane < 8) ka->out.global[env * 8 + lane] = my_global[lane];
+    uint8_t* g_hcids = reinterpret_cast<uint8_t*>(ka->out.h_card_ids) + env * (int64_t)cid_bytes;
+    const int pa = act_bytes >> 4, ph = hist_bytes >> 4, pc = cid_bytes >> 4;
+    const uint32_t misfit = (uint32_t)(act_bytes | hist_bytes | cid_bytes);
+    if (YGO_SKIP & 1024) {
+    } else if ((misfit & 15u) == 0 && pa + ph + pc <= 64) {
+      // all three images are whole 16-byte pieces at 16-byte aligned addresses (the default
+      // shapes): one load and one store per lane moves all of them
+      const int q = lane;
+      const bool in_a = q < pa, in_h = q < pa + ph;
+      const int piece = in_a ? q : (in_h ? q - pa : q - pa - ph);
+      const int src = (in_a ? cv.actions : (in_h ? cv.hact : cv.hcids)) + 16 * piece;
+      uint8_t* dst = (in_a ? g_actions : (in_h ? g_hact : g_hcids)) + 16 * piece;
+      if (q < pa + ph + pc) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint4 v = *reinterpret_cast<const uint4*>(lds + arena + src);
+        u32x4 raw;
+        __builtin_memcpy(&raw, &v, 16);
+#ifndef YGO_NO_NT_STORES
+        __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst));
+#else
+        *reinterpret_cast<u32x4*>(dst) = raw;
+#endif
+      }
+    } else {
+      wave_flush(g_actions, lds, arena + cv.actions + (int)((uintptr_t)g_actions & 15), act_bytes, lane);
+      wave_flush(g_hact, lds, arena + cv.hact + (int)((uintptr_t)g_hact & 15), hist_bytes, lane);
+      wave_flush(g_hcids, lds, arena + cv.hcids + (int)((uintptr_t)g_hcids & 14), cid_bytes, lane);
+    }
   };
 
   // Per env, in this order:
@@ -297,33 +329,25 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   {
     bool bad_u = false;   // raised in wave-uniform code
     uint32_t badv = 0;    // raised per lane (a VGPR flag: no exec-mask bookkeeping around it)
-    // LDS offsets congruent to the images' destinations modulo 16 (only the low bits matter here)
-    uint8_t *my_cards, *my_actions, *my_hact;
-    uint16_t* my_hcids;
-    {
-      KArgs ka = late_args();
-      const uint32_t e4 = (uint32_t)e & 15u;
-      my_cards = lds + arena + cv.cards + (int)(((uint32_t)(uintptr_t)ka->out.cards + e4 * (uint32_t)(R * 39)) & 15u);
-      my_actions = lds + arena + cv.actions + (int)(((uint32_t)(uintptr_t)ka->out.actions + e4 * (uint32_t)(a.max_options * nf)) & 15u);
-      my_hact = lds + arena + cv.hact + (int)(((uint32_t)(uintptr_t)ka->out.h_actions + e4 * (uint32_t)hist_bytes) & 15u);
-      my_hcids = reinterpret_cast<uint16_t*>(
-          lds + arena + cv.hcids + (int)(((uint32_t)(uintptr_t)ka->out.h_card_ids + e4 * (uint32_t)(a.max_options * a.mms * 2)) & 14u));
-    }
+    // LDS offsets congruent to the images' destinations modulo 16 (the output arrays themselves
+    // are 256-byte aligned: they are carved from the library's own slab, ygo.hip make_outs)
+    const uint32_t e4 = (uint32_t)e & 15u;
+    uint8_t* const my_cards = lds + arena + cv.cards + (int)((e4 * (uint32_t)(R * 39)) & 15u);
+    uint8_t* const my_actions = lds + arena + cv.actions + (int)((e4 * (uint32_t)(a.max_options * nf)) & 15u);
+    uint8_t* const my_hact = lds + arena + cv.hact + (int)((e4 * (uint32_t)hist_bytes) & 15u);
+    uint16_t* const my_hcids =
+        reinterpret_cast<uint16_t*>(lds + arena + cv.hcids + (int)((e4 * (uint32_t)(a.max_options * a.mms * 2)) & 14u));
 
     if (!(YGO_SKIP & 512)) wave_zero16(lds, arena + cv.actions, cv.zero_bytes - cv.actions, lane);
-    // ---- A ----
-    vm_wait<0>();
-    wave_fence();
-
-    // ---- B: header, every field a wave-uniform scalar ----
-    const uint4 hq = reinterpret_cast<const uint4*>(stage)[lane & 3];
+    // ---- B: header, every field a wave-uniform scalar. It comes by scalar loads straight from
+    // the record (the address is wave-uniform), not from the landing area: the segment walk
+    // below runs while the DMA is still in flight ----
     uint32_t w[16];
+    {
+      typedef const __attribute__((address_space(4))) uint32_t* KWords;
+      KWords hdr = (KWords)(uintptr_t)rec;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[4 * i + 0] = lane_word(hq.x, i);
-      w[4 * i + 1] = lane_word(hq.y, i);
-      w[4 * i + 2] = lane_word(hq.z, i);
-      w[4 * i + 3] = lane_word(hq.w, i);
+      for (int i = 0; i < 16; ++i) w[i] = hdr[i];
     }
     const int to_play = w[0] & 0xff;
     int n_opt = w[0] >> 24;
@@ -397,317 +421,313 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
     }
     const int n_listed = min(n_cards, R);
 
-    // the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128, l+192
-    // and option l; the history ring is held four bytes per lane. They stay PACKED (raw dwords)
-    // until the code that needs a field: unpacked early they cost 60 more VGPRs.
-    uint32_t cw[4][4];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack,defense
-    uint32_t mw[3 + EP_YGO_MAX_SPECS];  // option: feats[0..8], n_specs, pad | spec_key[max_multi_select]
-    // (read unconditionally, index clamped: a lane beyond the listed cards / the options holds
-    // words it never uses, and its hash probe coalesces with the last listed card's)
-    {  // second part of the record: listed cards beyond what the first fetch covered (if any)
-      const int need_pieces = (cv.off_cards >> 4) + n_listed;
-      if (need_pieces > n_dma_first * 64) {
-        fetch(n_dma_first, (need_pieces + 63) >> 6, need_pieces - 1);
-        vm_wait<0>();
-        wave_fence();
-      }
+    // obs:global_ (:1605-1620), eight bytes built as two wave-uniform words: lp of to_play and of
+    // the opponent (float_transform: high byte, low byte), phase id, "I am player 0", "it is my
+    // turn"; an env without options shows only byte 7 = 1 (:1839)
+    uint32_t glob0 = 0, glob1 = 1u << 24;
+    if (!no_options) {
+      const uint32_t turn_player = (w[0] >> 8) & 0xff, phase = w[6];
+      const uint32_t me = to_play == 0 ? w[4] : w[5], op = to_play == 0 ? w[5] : w[4];
+      glob0 = ((me >> 8) & 0xff) | ((me & 0xff) << 8) | (((op >> 8) & 0xff) << 16) | ((op & 0xff) << 24);
+      const bool phase_ok = phase != 0 && (phase & (phase - 1)) == 0 && phase <= 0x200;  // phase2id.at()
+      if (!phase_ok) bad_u = true;
+      glob1 = (phase_ok ? (uint32_t)(__ffs(phase) - 1) : 0u) | (to_play == 0 ? 1u << 8 : 0u) |
+              ((uint32_t)to_play == turn_player ? 1u << 16 : 0u);
     }
-    const int last_card = max(n_listed, 1) - 1;  // lanes without a card re-read the last listed one
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const uint4 c4 = reinterpret_cast<const uint4*>(stage + cv.off_cards)[min(lane + 64 * it, last_card)];  // one 16-byte read
-      cw[it][0] = c4.x; cw[it][1] = c4.y; cw[it][2] = c4.z; cw[it][3] = c4.w;
-    }
-    {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
-#pragma unroll
-      for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = d < 3 + a.mms ? src[d] : 0u;
-    }
-    uint32_t hw[2] = {0, 0};  // ring bytes [4*lane, 4*lane+4) and [256+4*lane, ...)
-    {
-      const uint32_t* ring_w = reinterpret_cast<const uint32_t*>(stage + cv.off_hist);
-      if (4 * lane < hist_bytes) hw[0] = ring_w[lane];
-      if (256 + 4 * lane < hist_bytes) hw[1] = ring_w[64 + lane];
-    }
-    // static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's cards are
-    // in flight together. (Unconditional loads: a lane without a card probes the slot of code 0,
-    // in bounds, and ignores the answer - a conditional load would make the compiler wait for
-    // each in turn.) An overlay material shows its static attack / defense (c_get_card copy,
-    // :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
-    uint4 tq[4], tq2[4];  // HashEntry: code | type | card_id, level, attr_id | race_id (both candidate slots)
-    const uint4* const table_q = reinterpret_cast<const uint4*>(a.table);
-    auto probe = [&](int it) {
-      if (!(YGO_SKIP & (32 | 64))) {
-        tq[it] = table_q[slot_a(cw[it][0], a.table_mask)];
-        tq2[it] = table_q[slot_b(cw[it][0], a.table_mul_b, a.table_mask)];
-      }
-      if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
-        tq[it] = tq2[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
-      if (YGO_SKIP & 32) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
-    };
-    probe(0);
-    if (n_listed > 64) {  // wave-uniform: most duel states list fewer than 64 cards
-      probe(1);
-      probe(2);
-      probe(3);
-    } else {
-#pragma unroll
-      for (int it = 1; it < 4; ++it) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
-    }
-    // rings longer than 512 bytes: the tail goes from the stage to the image now
-    if (hist_bytes > 512 && !no_options) {
-      const int shift = ha_p * nf;
-      for (int src = 512 + lane; src < hist_bytes; src += 64) {
-        int dst = src - shift;
-        if (dst < 0) dst += hist_bytes;
-        my_hact[dst] = (stage + cv.off_hist)[src];
-      }
-    }
-    YGO_STAMP(0);
 
-    YGO_STAMP(1);
-    // ---- D ----
-    wave_fence();
-    if (!(YGO_SKIP & 128)) wave_zero16(lds, arena + cv.cards, cv.actions, lane);
-    wave_fence();
+    // Everything from here on comes in two instantiations: NIT = 1 when the env lists at most 64
+    // cards (one per lane - nearly every duel state), NIT = 4 otherwise (lane l owns cards l,
+    // l+64, l+128, l+192). The choice is wave-uniform.
+    auto tail = [&](auto nit_c) {
+      constexpr int NIT = decltype(nit_c)::value;
+      // the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128, l+192
+      // and option l; the history ring is held four bytes per lane. They stay PACKED (raw dwords)
+      // until the code that needs a field: unpacked early they cost 60 more VGPRs.
+      uint32_t cw[NIT][4];   // ygo_card: code | controller,location,sequence,position | level,rank,link,is_material | attack,defense
+      uint32_t mw[3 + EP_YGO_MAX_SPECS];  // option: feats[0..8], n_specs, pad | spec_key[max_multi_select]
+      // (read unconditionally, index clamped: a lane beyond the listed cards / the options holds
+      // words it never uses, and its hash probe coalesces with the last listed card's)
+      // ---- A: the landing area is complete ----
+      vm_wait<0>();
+      wave_fence();
+      {  // second part of the record: listed cards beyond what the first fetch covered (if any)
+        const int need_pieces = (cv.off_cards >> 4) + n_listed;
+        if (NIT > 1 && need_pieces > n_dma_first * 64) {
+          fetch(n_dma_first, (need_pieces + 63) >> 6, need_pieces - 1);
+          vm_wait<0>();
+          wave_fence();
+        }
+      }
+      const int last_card = max(n_listed, 1) - 1;  // lanes without a card re-read the last listed one
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const uint4 c4 = reinterpret_cast<const uint4*>(stage + cv.off_cards)[min(lane + 64 * it, last_card)];  // one 16-byte read
+        cw[it][0] = c4.x; cw[it][1] = c4.y; cw[it][2] = c4.z; cw[it][3] = c4.w;
+      }
+      {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
+#pragma unroll
+        for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = d < 3 + a.mms ? src[d] : 0u;
+      }
+      // obs:h_actions_ is the ring rotated so that the newest entry is row 0 (:1881-1892): image
+      // row i = ring row (i + ha_p) mod n_history_actions. One lane per row, copied now (the
+      // landing area is about to be zeroed) in 8-byte pieces at byte granularity; the last piece
+      // ends with the row and may overlap the one before it (rows are 11..25 bytes).
+      if (!no_options && !(YGO_SKIP & 4)) {
+        const uint8_t* ring = stage + cv.off_hist;
+        const int hp = ha_p < a.n_hist ? ha_p : 0;
+        for (int i = lane; i < a.n_hist; i += 64) {
+          int srow = i + hp;
+          srow -= srow >= a.n_hist ? a.n_hist : 0;
+          const uint8_t* sp = ring + srow * nf;
+          uint8_t* dp = my_hact + i * nf;
+          uint64_t t0, t1 = 0, t2 = 0, tl;
+          __builtin_memcpy(&t0, sp, 8);
+          if (nf >= 16) __builtin_memcpy(&t1, sp + 8, 8);
+          if (nf >= 24) __builtin_memcpy(&t2, sp + 16, 8);
+          __builtin_memcpy(&tl, sp + nf - 8, 8);
+          __builtin_memcpy(dp, &t0, 8);
+          if (nf >= 16) __builtin_memcpy(dp + 8, &t1, 8);
+          if (nf >= 24) __builtin_memcpy(dp + 16, &t2, 8);
+          __builtin_memcpy(dp + nf - 8, &tl, 8);
+        }
+      }
+      // static data: cards_.at(code) / card_ids_.at(code). The first probes of a lane's cards are
+      // in flight together. (Unconditional loads: a lane without a card probes the slot of code 0,
+      // in bounds, and ignores the answer - a conditional load would make the compiler wait for
+      // each in turn.) An overlay material shows its static attack / defense (c_get_card copy,
+      // :2109-2114): they replace the (absent) dynamic ones in the lane's copy.
+      uint4 tq[NIT], tq2[NIT];  // HashEntry: code | type | card_id, level, attr_id | race_id (both candidate slots)
+      const char* const table_b = reinterpret_cast<const char*>(a.table);  // (32-bit byte offsets: the table is < 4 GiB)
+      auto probe = [&](int it) {
+        if (!(YGO_SKIP & (32 | 64))) {
+          tq[it] = *reinterpret_cast<const uint4*>(table_b + (slot_a(cw[it][0], a.table_mask) << 4));
+          tq2[it] = *reinterpret_cast<const uint4*>(table_b + (slot_b(cw[it][0], a.table_mul_b, a.table_mask) << 4));
+        }
+        if (YGO_SKIP & 64)  // priced without the table read: a made-up known card
+          tq[it] = tq2[it] = make_uint4(cw[it][0], kEntryValid | 1u | (1u << (4 + (cw[it][0] & 7))), (cw[it][0] & 0xffff) | (4u << 16) | (1u << 24), 1u);
+        if (YGO_SKIP & 32) tq[it] = tq2[it] = make_uint4(0, 0, 0, 0);
+      };
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) probe(it);
+      YGO_STAMP(0);
 
-    // ---- E: hidden opponent locations get placeholder rows {col2 = location id, col4 = 1}
-    // (:1526-1532); obs:global_ (:1605-1620) ----
-#pragma unroll
-    for (int ph = 0; ph < 3; ++ph)
-      for (int q = lane; q < ph_cnt[ph] && !(YGO_SKIP & 256); q += 64) {
-        uint8_t* prow = my_cards + (ph_row[ph] + q) * 39;
-        prow[2] = (uint8_t)(ph == 0 ? 1 : (ph == 1 ? 2 : 7));
-        prow[4] = 1;
+      YGO_STAMP(1);
+      // ---- D ----
+      wave_fence();
+      if (!(YGO_SKIP & 128)) wave_zero16(lds, arena + cv.cards, cv.actions, lane);
+      wave_fence();
+
+      // ---- E: hidden opponent locations get placeholder rows {col2 = location id, col4 = 1}
+      // (:1526-1532); obs:global_ (:1605-1620) ----
+      // DECK and HAND placeholders are adjacent rows (the hidden HAND follows the DECK directly);
+      // the EXTRA ones come after the listed segments
+      if (!(YGO_SKIP & 256)) {
+        const int c0 = ph_cnt[0], c01 = ph_cnt[0] + ph_cnt[1], call = c01 + ph_cnt[2];
+        for (int q = lane; q < call; q += 64) {
+          uint8_t* prow = my_cards + (q < c01 ? ph_row[0] + q : ph_row[2] + (q - c01)) * 39;
+          prow[2] = (uint8_t)(q < c0 ? 1 : (q < c01 ? 2 : 7));
+          prow[4] = 1;
+        }
       }
-    if (lane == 0) {
-      if (no_options) {
-        my_global[7] = 1;  // :1839
-      } else {
-        const int turn_player = (w[0] >> 8) & 0xff;
-        const uint32_t phase = w[6];
-        ft((int)(to_play == 0 ? w[4] : w[5]), my_global[0], my_global[1]);
-        ft((int)(to_play == 0 ? w[5] : w[4]), my_global[2], my_global[3]);
-        if (phase == 0 || (phase & (phase - 1)) != 0 || phase > 0x200) badv = 1;
-        else my_global[4] = (uint8_t)(__ffs(phase) - 1);  // phase2id: 0..9
-        my_global[5] = to_play == 0 ? 1 : 0;
-        my_global[6] = to_play == turn_player ? 1 : 0;
+      // (work that needs no card data goes here, under the latency of the hash probes)
+      // the nine spec-independent feature bytes of each option (columns 2*mms .. 2*mms+8)
+      if (lane < n_opt && !(YGO_SKIP & 8)) {  // (the image is zero: writing zeros changes nothing)
+        uint8_t* frow = my_actions + lane * nf + 2 * a.mms;
+        __builtin_memcpy(frow, &mw[0], 8);
+        frow[8] = (uint8_t)mw[2];
       }
-    }
-    // (work that needs no card data goes here, under the latency of the hash probes)
-    // ---- obs:h_actions_ : ring rotated so that the newest entry is row 0 (:1881-1892) ----
-    if (!no_options && !(YGO_SKIP & 4)) {
-      const int shift = ha_p * nf;
+      YGO_STAMP(2);
+
+      // ---- F: the entry is the candidate whose code matches (neither: the card is unknown). An
+      // overlay material shows its static attack / defense (c_get_card copy, :2109-2114), fetched
+      // from the parallel table now that the slot is known: they replace the (absent) dynamic ones.
 #pragma unroll
-      for (int ww = 0; ww < 2; ++ww) {
+      for (int it = 0; it < NIT; ++it) {
+        const bool hit_a = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
+        if (!hit_a) tq[it] = tq2[it];
+        if ((cw[it][2] >> 24) != 0 && lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) {
+          const uint32_t slot = hit_a ? slot_a(cw[it][0], a.table_mask) : slot_b(cw[it][0], a.table_mul_b, a.table_mask);
+          const uint2 x = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.table_aux) + (slot << 3));
+          cw[it][3] = (x.x & 0xffff) | (x.y << 16);
+        }
+      }
+      // every table read has returned (make the compiler settle them here: a wait for one of them
+      // after the prefetch below would also wait for the prefetch)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int src = 256 * ww + 4 * lane + bb;  // ring byte held by this lane
-          const uint8_t v = (uint8_t)(hw[ww] >> (8 * bb));
-          if (src < hist_bytes && v) {
-            int dst = src - shift;
-            if (dst < 0) dst += hist_bytes;
-            my_hact[dst] = v;
+      for (int it = 0; it < NIT; ++it)
+        asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]) : : "memory");
+      YGO_STAMP(3);
+
+      // ---- C: scalars + Env::Allocate common fields (env.h:196-222). Issued only now: VMEM retires
+      // in issue order, so stores in front of the probe wait above would have put their
+      // acknowledgement latency into it ----
+      if (lane == 0 && !(YGO_SKIP & 2048)) {
+        KArgs ka = late_args();
+        const bool done = (w[1] >> 24) != 0;
+        const int elapsed = (int)w[3];
+        ka->out.env_id[e] = (int)w[2];
+        ka->out.penv[e] = (int)w[2];
+        ka->out.elapsed[e] = elapsed;
+        ka->out.done[e] = done;
+        ka->out.reward[e] = __uint_as_float(w[8]);
+        ka->out.discount[e] = done ? 0.f : 1.f;
+        ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
+        ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
+        ka->out.num_options[e] = no_options ? 1 : n_opt;
+        ka->out.to_play[e] = to_play;
+        ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
+        ka->out.win_reason[e] = (int)w[7];
+        *reinterpret_cast<uint2*>(ka->out.global + e * 8) = make_uint2(glob0, glob1);
+      }
+
+
+      // ---- H ----
+      // ---- obs:cards_ : one lane per LISTED card (:1508-1603), written branch-free: the 14 leading
+      // bytes of a row are computed with selects (hidden fields as zeros, which is what the zeroed
+      // image holds anyway) and leave as three dwords and a short; only the type flags loop.
+      // Every listed row also enters the env's direct-mapped spec table (the reference's per-step
+      // spec2index hash map, :1549). ----
+      int ti_of[NIT];
+      uint32_t row1_of[NIT], key_of[NIT];  // spec-table slot, 1-based row and spec key of the lane's cards
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        // one card at a time, unpacked here and no earlier
+        asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
+        const int k = lane + 64 * it;
+        ti_of[it] = -1;
+        row1_of[it] = 0;
+        key_of[it] = 0xffffffffu;
+        if (k < n_listed && !(YGO_SKIP & 1)) {
+          const uint32_t pi = k >= n0 ? 1u : 0u;
+          uint32_t key = 0xffffffffu;
+          if (k < (pi ? fit_end1 : fit_end0)) {
+            const uint32_t c1 = cw[it][1], c2 = cw[it][2];
+            const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
+            const bool in_hand1 = (k >= hand1_lo) & (k < hand1_hi);
+            const int r = k + (pi ? shift1 : 0);
+            const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
+            // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
+            const bool loc_ok = (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
+            const uint32_t lid = loc_ok ? (uint32_t)__ffs(loc7) : 0u;  // location2id
+            // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
+            const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * (pos & 15))) & 0xf : 0xfu;
+            const bool known = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
+            const bool revealed = in_hand1 & (seq < 64) & (((hand_mask >> (seq & 63)) & 1ull) != 0);  // :1541-1545
+            bool hide = (pi != 0) & ((pos & 0xa) != 0) & !revealed;                                   // POS_FACEDOWN (:1540)
+            hide = (hide & (overlay == 0)) | !known;                                                  // :1562-1564
+            const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
+            badv |= (!known | !loc_ok | ((overlay == 0) & (pid == 0xf)) | (!hide & ((attr == 0xff) | (race == 0xff)))) ? 1u : 0u;
+            const uint32_t lv = c2 & 0xff, rk = (c2 >> 8) & 0xff, lk = (c2 >> 16) & 0xff;
+            uint32_t level = lv ? lv : tlevel;  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
+            level = rk ? rk : level;
+            level = lk ? lk : level;
+            level = (c2 >> 24) ? tlevel : level;  // an overlay material shows its static level
+            // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
+            const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][3] >> 16;
+            const uint32_t show = hide ? 0u : 0xffffffffu;
+            const uint32_t b3 = ((loc7 == 0x04) | (loc7 == 0x08) | (loc7 == 0x10)) ? seq + 1 : 0u;  // :1573-1578
+            const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
+            const uint32_t w0 = (((cid >> 8) | ((cid & 0xff) << 8)) & show) | (lid << 16) | ((b3 & 0xff) << 24);
+            const uint32_t w1 = (ctrl != (uint32_t)to_play ? 1u : 0u) | (b5 << 8) | (overlay << 16) | (((attr == 0xff ? 0u : attr) << 24) & show);
+            const uint32_t w2 = ((race == 0xff ? 0u : race) | (level << 8) | ((atk >> 8) << 16) | ((atk & 0xff) << 24)) & show;
+            const uint16_t w3 = (uint16_t)(((def >> 8) | ((def & 0xff) << 8)) & show);
+            uint8_t* row = my_cards + r * 39;
+            __builtin_memcpy(row, &w0, 4);
+            __builtin_memcpy(row + 4, &w1, 4);
+            __builtin_memcpy(row + 8, &w2, 4);
+            __builtin_memcpy(row + 12, &w3, 2);
+            // type_to_ids (:635-642): one byte per TYPE_* key in ascending order (the table holds the
+            // flags already compacted to bits 0..24); set bits only
+            uint32_t tb = tq[it].y & 0x01ffffffu & show;
+            while (tb) {
+              const int b = __ffs(tb) - 1;
+              tb &= tb - 1;
+              row[14 + b] = 1;
+            }
+            const uint32_t suf = overlay ? (pos + 1) & 0xff : 0u;
+            key = pi | (loc7 << 8) | (seq << 16) | (suf << 24);
+            const int ti_plain = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
+            const int ti_over = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
+            const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
+            const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
+            const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
+            if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
+            ti_of[it] = ti;
+            row1_of[it] = (uint32_t)(r + 1) & 0xff;
+            key_of[it] = key;
           }
         }
       }
-    }
-    // the nine spec-independent feature bytes of each option (columns 2*mms .. 2*mms+8)
-    if (lane < n_opt && !(YGO_SKIP & 8)) {
-      uint8_t* frow = my_actions + lane * nf + 2 * a.mms;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const uint8_t f = (uint8_t)(mw[k >> 2] >> (8 * (k & 3)));
-        if (f) frow[k] = f;
+      wave_fence();
+      // obs:cards_ is complete: its 5.7 KB leave the CU now, under the option phase (which only
+      // reads the image), instead of at the very end of the wave's life
+      if (!(YGO_SKIP & 16)) {
+        uint8_t* g_cards = late_args()->out.cards + e * (int64_t)(R * 39);
+        wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
       }
-    }
-    YGO_STAMP(2);
-
-    // ---- F: the entry is the candidate whose code matches (neither: the card is unknown). An
-    // overlay material shows its static attack / defense (c_get_card copy, :2109-2114), fetched
-    // from the parallel table now that the slot is known: they replace the (absent) dynamic ones.
+      YGO_STAMP(4);
+      // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
+      // one of them, the reference the LAST one; detect it and take the exact scan instead
+      bool dup = false;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const bool hit_a = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
-      if (!hit_a) tq[it] = tq2[it];
-      if ((cw[it][2] >> 24) != 0 && lane + 64 * it < n_listed && !(YGO_SKIP & (32 | 64))) {
-        const uint32_t slot = hit_a ? slot_a(cw[it][0], a.table_mask) : slot_b(cw[it][0], a.table_mul_b, a.table_mask);
-        const uint2 x = reinterpret_cast<const uint2*>(a.table_aux)[slot];
-        cw[it][3] = (x.x & 0xffff) | (x.y << 16);
-      }
-    }
-    // every table read has returned (make the compiler settle them here: a wait for one of them
-    // after the prefetch below would also wait for the prefetch)
+      for (int it = 0; it < NIT; ++it)
+        if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[ti_of[it]] != row1_of[it]) dup = true;
+      dup = __any(dup);
+      // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      asm volatile("" : "+v"(tq[it].x), "+v"(tq[it].y), "+v"(tq[it].z), "+v"(tq[it].w), "+v"(cw[it][3]) : : "memory");
-    YGO_STAMP(3);
-
-    // ---- C: scalars + Env::Allocate common fields (env.h:196-222). Issued only now: VMEM retires
-    // in issue order, so stores in front of the probe wait above would have put their
-    // acknowledgement latency into it ----
-    if (lane == 0 && !(YGO_SKIP & 2048)) {
-      KArgs ka = late_args();
-      const bool done = (w[1] >> 24) != 0;
-      const int elapsed = (int)w[3];
-      ka->out.env_id[e] = (int)w[2];
-      ka->out.penv[e] = (int)w[2];
-      ka->out.elapsed[e] = elapsed;
-      ka->out.done[e] = done;
-      ka->out.reward[e] = __uint_as_float(w[8]);
-      ka->out.discount[e] = done ? 0.f : 1.f;
-      ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
-      ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
-      ka->out.num_options[e] = no_options ? 1 : n_opt;
-      ka->out.to_play[e] = to_play;
-      ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
-      ka->out.win_reason[e] = (int)w[7];
-    }
-
-
-    // ---- H ----
-    // ---- obs:cards_ : one lane per LISTED card (:1508-1603), written branch-free: the 14 leading
-    // bytes of a row are computed with selects (hidden fields as zeros, which is what the zeroed
-    // image holds anyway) and leave as three dwords and a short; only the type flags loop.
-    // Every listed row also enters the env's direct-mapped spec table (the reference's per-step
-    // spec2index hash map, :1549). ----
-    int ti_of[4];
-    uint32_t row1_of[4], key_of[4];  // spec-table slot, 1-based row and spec key of the lane's cards
+      for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) asm volatile("" : "+v"(mw[d]));
+      if (!(YGO_SKIP & 8)) {
+        uint8_t* arow = my_actions + lane * nf;
+        const int ns = lane < n_opt ? min((int)((mw[2] >> 8) & 0xff), a.mms) : 0;
+        bool open = true;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      // one card at a time, unpacked here and no earlier
-      asm volatile("" : "+v"(cw[it][0]), "+v"(cw[it][1]), "+v"(cw[it][2]), "+v"(tq[it].z) : : "memory");
-      const int k = lane + 64 * it;
-      ti_of[it] = -1;
-      row1_of[it] = 0;
-      key_of[it] = 0xffffffffu;
-      if (k < n_listed && !(YGO_SKIP & 1)) {
-        const uint32_t pi = k >= n0 ? 1u : 0u;
-        uint32_t key = 0xffffffffu;
-        if (k < (pi ? fit_end1 : fit_end0)) {
-          const uint32_t c1 = cw[it][1], c2 = cw[it][2];
-          const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
-          const bool in_hand1 = (k >= hand1_lo) & (k < hand1_hi);
-          const int r = k + (pi ? shift1 : 0);
-          const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
-          // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
-          const bool loc_ok = (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
-          const uint32_t lid = loc_ok ? (uint32_t)__ffs(loc7) : 0u;  // location2id
-          // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
-          const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * (pos & 15))) & 0xf : 0xfu;
-          const bool known = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
-          const bool revealed = in_hand1 & (seq < 64) & (((hand_mask >> (seq & 63)) & 1ull) != 0);  // :1541-1545
-          bool hide = (pi != 0) & ((pos & 0xa) != 0) & !revealed;                                   // POS_FACEDOWN (:1540)
-          hide = (hide & (overlay == 0)) | !known;                                                  // :1562-1564
-          const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
-          badv |= (!known | !loc_ok | ((overlay == 0) & (pid == 0xf)) | (!hide & ((attr == 0xff) | (race == 0xff)))) ? 1u : 0u;
-          const uint32_t lv = c2 & 0xff, rk = (c2 >> 8) & 0xff, lk = (c2 >> 16) & 0xff;
-          uint32_t level = lv ? lv : tlevel;  // dynamic overrides of get_cards_in_location (:2090-2099, :2126-2133)
-          level = rk ? rk : level;
-          level = lk ? lk : level;
-          level = (c2 >> 24) ? tlevel : level;  // an overlay material shows its static level
-          // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
-          const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][3] >> 16;
-          const uint32_t show = hide ? 0u : 0xffffffffu;
-          const uint32_t b3 = ((loc7 == 0x04) | (loc7 == 0x08) | (loc7 == 0x10)) ? seq + 1 : 0u;  // :1573-1578
-          const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
-          const uint32_t w0 = (((cid >> 8) | ((cid & 0xff) << 8)) & show) | (lid << 16) | ((b3 & 0xff) << 24);
-          const uint32_t w1 = (ctrl != (uint32_t)to_play ? 1u : 0u) | (b5 << 8) | (overlay << 16) | (((attr == 0xff ? 0u : attr) << 24) & show);
-          const uint32_t w2 = ((race == 0xff ? 0u : race) | (level << 8) | ((atk >> 8) << 16) | ((atk & 0xff) << 24)) & show;
-          const uint16_t w3 = (uint16_t)(((def >> 8) | ((def & 0xff) << 8)) & show);
-          uint8_t* row = my_cards + r * 39;
-          __builtin_memcpy(row, &w0, 4);
-          __builtin_memcpy(row + 4, &w1, 4);
-          __builtin_memcpy(row + 8, &w2, 4);
-          __builtin_memcpy(row + 12, &w3, 2);
-          // type_to_ids (:635-642): one byte per TYPE_* key in ascending order (the table holds the
-          // flags already compacted to bits 0..24); set bits only
-          uint32_t tb = tq[it].y & 0x01ffffffu & show;
-          while (tb) {
-            const int b = __ffs(tb) - 1;
-            tb &= tb - 1;
-            row[14 + b] = 1;
-          }
-          const uint32_t suf = overlay ? (pos + 1) & 0xff : 0u;
-          key = pi | (loc7 << 8) | (seq << 16) | (suf << 24);
-          const int ti_plain = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
-          const int ti_over = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
-          const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
-          const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
-          const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
-          if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
-          ti_of[it] = ti;
-          row1_of[it] = (uint32_t)(r + 1) & 0xff;
-          key_of[it] = key;
-        }
-      }
-    }
-    wave_fence();
-    // obs:cards_ is complete: its 5.7 KB leave the CU now, under the option phase (which only
-    // reads the image), instead of at the very end of the wave's life
-    if (!(YGO_SKIP & 16)) {
-      uint8_t* g_cards = late_args()->out.cards + e * (int64_t)(R * 39);
-      wave_flush(g_cards, lds, arena + cv.cards + (int)((uintptr_t)g_cards & 15), R * 39, lane);
-    }
-    YGO_STAMP(4);
-    // two rows with one spec (never in a consistent duel state): the table holds an arbitrary
-    // one of them, the reference the LAST one; detect it and take the exact scan instead
-    bool dup = false;
+        for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
+          if (__any(j < ns)) {  // wave-uniform: the exact scan below is a whole-wave affair
+            const bool act = j < ns;
+            const uint32_t key = mw[3 + j];
+            const int ti = spec_slot(key, a.max_cards);
+            const bool fast = act & (ti >= 0) & !dup;
+            int idx = 0;
+            if (fast) idx = my_spec[ti];
+            // A key outside the direct-mapped table, or an env with two rows under one spec: the
+            // exact search, last row wins (:1549). Rare; done by the whole wave for one option at a
+            // time - every lane compares the key with the cards it owns, then a wave-wide maximum.
+            uint64_t need = __ballot(act & !fast);
+            while (need) {
+              const int src = __ffsll((unsigned long long)need) - 1;
+              need &= need - 1;
+              const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
+              int best = 0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[ti_of[it]] != row1_of[it]) dup = true;
-    dup = __any(dup);
-    // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
+              for (int it = 0; it < NIT; ++it)
+                if (key_of[it] == want) best = max(best, (int)row1_of[it]);
 #pragma unroll
-    for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) asm volatile("" : "+v"(mw[d]));
-    if (!(YGO_SKIP & 8)) {
-      uint8_t* arow = my_actions + lane * nf;
-      const int ns = lane < n_opt ? min((int)((mw[2] >> 8) & 0xff), a.mms) : 0;
-      bool open = true;
-#pragma unroll
-      for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
-        if (__any(j < ns)) {  // wave-uniform: the exact scan below is a whole-wave affair
-          const bool act = j < ns;
-          const uint32_t key = mw[3 + j];
-          const int ti = spec_slot(key, a.max_cards);
-          const bool fast = act & (ti >= 0) & !dup;
-          int idx = 0;
-          if (fast) idx = my_spec[ti];
-          // A key outside the direct-mapped table, or an env with two rows under one spec: the
-          // exact search, last row wins (:1549). Rare; done by the whole wave for one option at a
-          // time - every lane compares the key with the cards it owns, then a wave-wide maximum.
-          uint64_t need = __ballot(act & !fast);
-          while (need) {
-            const int src = __ffsll((unsigned long long)need) - 1;
-            need &= need - 1;
-            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
-            int best = 0;
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-              if (key_of[it] == want) best = max(best, (int)row1_of[it]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
-            if (lane == src) idx = best;
-          }
-          if (act) {
-            badv |= idx == 0 ? 1u : 0u;  // spec2index.at(spec) throws
-            arow[2 * j] = (uint8_t)(idx >> 8);
-            arow[2 * j + 1] = (uint8_t)(idx & 0xff);
-            // read back from the images, literally: low byte only (Q7), stop at the first zero
-            const int spec_index = idx & 0xff;
-            if (spec_index == 0) open = false;
-            if (open) {
-              const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
-              my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
+              for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+              if (lane == src) idx = best;
+            }
+            if (act) {
+              badv |= idx == 0 ? 1u : 0u;  // spec2index.at(spec) throws
+              arow[2 * j] = (uint8_t)(idx >> 8);
+              arow[2 * j + 1] = (uint8_t)(idx & 0xff);
+              // read back from the images, literally: low byte only (Q7), stop at the first zero
+              const int spec_index = idx & 0xff;
+              if (spec_index == 0) open = false;
+              if (open) {
+                const uint16_t c1 = my_cards[(spec_index - 1) * 39 + 0], c2 = my_cards[(spec_index - 1) * 39 + 1];
+                my_hcids[lane * a.mms + j] = (uint16_t)((c1 << 8) + c2);
+              }
             }
           }
         }
       }
-    }
-    YGO_STAMP(5);
-    if ((bad_u || __any(badv != 0)) && lane == 0) *late_args()->err = 1u;
-    wave_fence();
-    flush_env(e, lane);
+      YGO_STAMP(5);
+      if ((bad_u || __any(badv != 0)) && lane == 0) *late_args()->err = 1u;
+      wave_fence();
+      flush_env(e, lane);
+    };
+    if (n_listed <= 64) tail(std::integral_constant<int, 1>{});
+    else tail(std::integral_constant<int, 4>{});
     YGO_STAMP(6);
   }
 }

@@ -1,4 +1,5 @@
 #!/bin/bash
+shopt -s nullglob
 # GPU box: dynamic instruction counts per env for the default build and the phase-skipping builds.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_ygo_skip

@@ -1,4 +1,5 @@
 #!/bin/bash
+shopt -s nullglob
 # GPU box: price each phase of the encode kernel by timing diagnostic builds that leave it out.
 mkdir -p gpurun_out
 export EP_YGO_CPU_SECONDS=0

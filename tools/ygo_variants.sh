@@ -1,4 +1,5 @@
 #!/bin/bash
+shopt -s nullglob
 # GPU box: parity tests with the default build, then the large-batch bench for each variant build.
 set -e
 mkdir -p gpurun_out
