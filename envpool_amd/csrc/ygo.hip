@@ -817,7 +817,7 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
   const size_t opt_bytes = (size_t)ygk::option_bytes(cfg->max_multi_select);
   for (int i = 0; i < n_opt; ++i) {
     ygo_option_head* oh = (ygo_option_head*)(rec + lay.off_opts + (size_t)i * opt_bytes);
-    uint32_t* keys = (uint32_t*)(oh + 1);
+    uint32_t* keys = (uint32_t*)(oh + 1);  // spec references (ygo_kernels.hpp spec_ref)
     std::vector<std::string> specs;
     if (!in->options[i]) return fail(EP_ERR_INVALID, "null option string");
     if ((rc = parse_option(in->msg, in->options[i], oh->feats, &specs))) return rc;
@@ -827,7 +827,8 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
     for (size_t j = 0; j < specs.size(); ++j) {
       // a malformed spec can never be a key of spec2index: give it a key no row carries, so the
       // device reports the same "throw" the reference's .at() would
-      if (!spec_key(specs[j], &keys[j])) keys[j] = 0xfffffffeu;
+      uint32_t key;
+      keys[j] = spec_key(specs[j], &key) ? ygk::spec_ref(key, cfg->max_cards) : ygk::kSpecNone;
     }
   }
   return EP_OK;

@@ -136,15 +136,29 @@ __host__ __device__ inline uint32_t type_bit(int j) {  // ascending TYPE_* keys 
 // Slot of a spec key in the direct-mapped table, or -1 when the key is outside it (then the
 // exact linear scan is used): plain specs by (opponent, location, sequence < max_cards), overlay
 // specs by (opponent, monster zone < 8, letter < 8).
-__device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
+__host__ __device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
   // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
   const uint32_t opp = key & 0xff, loc7 = (key >> 8) & 0xff, seq = (key >> 16) & 0xff, suf = key >> 24;
   const bool loc_ok = (opp <= 1) & (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
   const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)max_cards);
   const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
-  const int ti_plain = (int)((opp * 7 + (uint32_t)__ffs(loc7) - 1) * (uint32_t)max_cards + seq);
+  const int ti_plain = (int)((opp * 7 + (uint32_t)__builtin_ffs((int)loc7) - 1) * (uint32_t)max_cards + seq);
   const int ti_over = 14 * max_cards + (int)((opp * 8 + seq) * 8 + (suf - 1));
   return plain_ok ? ti_plain : (over_ok ? ti_over : -1);
+}
+__host__ __device__ __forceinline__ int spec_slots(int max_cards) { return 14 * max_cards + 128; }
+
+// What a record stores per referenced spec ("spec reference"), and what the device derives for
+// every card row to compare against it in the exact search: the slot in the direct-mapped table
+// when the spec has one (an injective code of such specs), else bit 31 | the spec itself,
+// opponent | location << 1 | sequence << 8 | suffix << 16. kSpecNone matches no row.
+constexpr uint32_t kSpecNone = 0xfffffffeu;
+__host__ __device__ __forceinline__ uint32_t spec_ref(uint32_t key, int max_cards) {
+  const int ti = spec_slot(key, max_cards);
+  if (ti >= 0) return (uint32_t)ti;
+  const uint32_t opp = key & 0xff, loc = (key >> 8) & 0xff, seq = (key >> 16) & 0xff, suf = key >> 24;
+  if (opp > 1 || loc > 0x7f) return kSpecNone;
+  return 0x80000000u | opp | (loc << 1) | (seq << 8) | (suf << 16);
 }
 
 #ifndef YGO_SKIP
@@ -597,10 +611,9 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         const int k = lane + 64 * it;
         ti_of[it] = -1;
         row1_of[it] = 0;
-        key_of[it] = 0xffffffffu;
+        key_of[it] = kSpecNone;
         if (k < n_listed && !(YGO_SKIP & 1)) {
           const uint32_t pi = k >= n0 ? 1u : 0u;
-          uint32_t key = 0xffffffffu;
           if (k < (pi ? fit_end1 : fit_end0)) {
             const uint32_t c1 = cw[it][1], c2 = cw[it][2];
             const uint32_t ctrl = c1 & 0xff, loc = (c1 >> 8) & 0xff, seq = (c1 >> 16) & 0xff, pos = c1 >> 24;
@@ -646,7 +659,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
               row[14 + b] = 1;
             }
             const uint32_t suf = overlay ? (pos + 1) & 0xff : 0u;
-            key = pi | (loc7 << 8) | (seq << 16) | (suf << 24);
             const int ti_plain = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
             const int ti_over = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
             const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
             if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
             ti_of[it] = ti;
             row1_of[it] = (uint32_t)(r + 1) & 0xff;
-            key_of[it] = key;
+            key_of[it] = ti >= 0 ? (uint32_t)ti : 0x80000000u | pi | (loc7 << 1) | (seq << 8) | (suf << 16);
           }
         }
       }
@@ -685,11 +697,10 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         for (int j = 0; j < EP_YGO_MAX_SPECS; ++j) {
           if (__any(j < ns)) {  // wave-uniform: the exact scan below is a whole-wave affair
             const bool act = j < ns;
-            const uint32_t key = mw[3 + j];
-            const int ti = spec_slot(key, a.max_cards);
-            const bool fast = act & (ti >= 0) & !dup;
+            const uint32_t key = mw[3 + j];  // spec reference: a table slot, or bit 31 | the spec
+            const bool fast = act & (key < (uint32_t)spec_slots(a.max_cards)) & !dup;
             int idx = 0;
-            if (fast) idx = my_spec[ti];
+            if (fast) idx = my_spec[key];
             // A key outside the direct-mapped table, or an env with two rows under one spec: the
             // exact search, last row wins (:1549). Rare; done by the whole wave for one option at a
             // time - every lane compares the key with the cards it owns, then a wave-wide maximum.

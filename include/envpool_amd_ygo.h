@@ -46,7 +46,7 @@ typedef struct {
  * record := ygo_header (64 B)
  *           | history ring of the to_play player, n_history_actions*n_action_feats bytes,
  *             raw ring order (ygopro.h:1304-1314), padded to 16 B
- *           | max_options x { ygo_option_head, uint32_t spec_key[max_multi_select] }, padded to 16 B
+ *           | max_options x { ygo_option_head, uint32_t spec_ref[max_multi_select] }, padded to 16 B
  *           | ygo_card[2*max_cards]        (only the first sum(loc_count of listed
  *                                           locations) entries are meaningful: the device
  *                                           fetches that prefix only)
@@ -100,9 +100,16 @@ typedef struct {
   uint8_t feats[9];  /* msg, act(+offset), yes/no, phase, cancel/finish, position, option, place, attrib */
   uint8_t n_specs;   /* 0..max_multi_select */
   uint8_t pad[2];
-} ygo_option_head; /* 12 bytes, followed by uint32_t spec_key[max_multi_select]:
-   * key = opponent | (location&0x7f)<<8 | sequence<<16 | (has_suffix ? pos+1 : 0)<<24,
-   * "opponent" relative to to_play (a leading 'o', :358-365); suffix = overlay letter (:352-354) */
+} ygo_option_head; /* 12 bytes, followed by uint32_t spec_ref[max_multi_select], one per referenced
+   * spec (spec_to_ls, :352-400: an 'o' prefix = opponent relative to to_play, a location letter,
+   * a 1-based sequence, an optional overlay letter). With loc = LOCATION_* & 0x7f, seq 0-based
+   * and suf = letter - 'a' + 1 (0 without one):
+   *   plain spec, seq < max_cards:              (opp*7 + location_id-1) * max_cards + seq
+   *   overlay spec on MZONE, seq < 8, suf <= 8: 14*max_cards + (opp*8 + seq)*8 + suf-1
+   *   any other spec:                           0x80000000 | opp | loc<<1 | seq<<8 | suf<<16
+   *   not a spec at all:                        0xfffffffe (matches no row)
+   * The first two are the row's slot in the device's per-env spec table (the reference's
+   * spec2index, :1549); ep_ygo_emit_record computes them. */
 
 /* ---- static card table (replaces init_module's cards_/card_ids_, ygopro.h:1030-1064) -- */
 typedef struct {

@@ -110,7 +110,8 @@ def test_emitter_record_fields():
   opt0 = rec[off_opts:off_opts + 12 + 4 * 5]
   assert opt0[0] == 3 and opt0[9] == 2  # msg id, n_specs
   keys = np.frombuffer(opt0[12:20].tobytes(), "<u4").tolist()
-  assert keys == [0 | (0x04 << 8) | (0 << 16) | (1 << 24), 1 | (0x02 << 8) | (0 << 16)]
+  # spec references: "m1a" -> overlay slot 14*max_cards + (0*8 + 0)*8 + 0; "oh1" -> plain slot (1*7 + 2-1)*max_cards + 0
+  assert keys == [14 * 75, 8 * 75]
 
 
 @pytest.mark.parametrize("msg,opt,feat_col,val", [
