@@ -68,7 +68,13 @@ struct Carve {
 };
 // direct-mapped spec table of one env: [2 players][7 locations][max_cards sequences] plus
 // [2][8 monster zones][8 overlay letters], one byte each (1-based row index, 0 = absent)
+#ifdef YGO_FAKE_SPEC  // diagnostic builds: a tiny (wrong) spec table, to price a smaller LDS arena
+__host__ __device__ inline int spec_table_bytes(int) { return YGO_FAKE_SPEC; }
+#define YGO_SPEC_IX(x) ((x) & (YGO_FAKE_SPEC - 1))
+#else
 __host__ __device__ inline int spec_table_bytes(int max_cards) { return al16(14 * max_cards + 128); }
+#define YGO_SPEC_IX(x) (x)
+#endif
 __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_hist, int mms) {
   const int nf = 9 + 2 * mms, R = 2 * max_cards;
   Carve c;
@@ -83,7 +89,7 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.actions = o; o += al16(max_options * nf) + 16;
   c.hact = o;    o += al16(n_hist * nf) + 16;
   c.hcids = o;   o += al16(max_options * mms * 2) + 16;
-  c.global = o;  o += 16;
+  c.global = o;  // (obs:global_ is built in scalar registers: no LDS image)
   c.spec_stride = spec_table_bytes(max_cards);
   c.spec = o;    o += c.spec_stride;
   c.zero_bytes = o;
@@ -263,7 +269,10 @@ __device__ __forceinline__ KArgs late_args() {
   return p;
 }
 
-__global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
+#ifndef YGO_OCC
+#define YGO_OCC 5  // waves per SIMD the register budget is sized for (the LDS arena allows 20 per CU)
+#endif
+__global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const Carve& cv = a.cv;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -280,19 +289,18 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
   uint8_t* const my_spec = lds + arena + cv.spec;
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
-  // The record is fetched in two parts: everything up to the card array plus the first 64 cards
-  // at once (whole 1 KiB DMA instructions), the rest of the LISTED cards once the header has told
-  // how many there are - the unused tail of the card array never leaves HBM. `last` is the last
-  // 16-byte piece wanted: lanes past it re-read it (same cache line, no extra traffic).
+  // The record is fetched in two parts: its first KiB at once (one DMA instruction), the rest up
+  // to the last LISTED card once the header (scalar loads, below) has told how many there are -
+  // the unused tail of the card array never leaves HBM. `last` is the last 16-byte piece wanted:
+  // lanes past it re-read it (same cache line, no extra traffic).
   const uint8_t* const rec = a.records + e * a.stride;
-  const int n_dma_first = min((cv.off_cards + 64 * (int)sizeof(ygo_card) + 1023) >> 10, cv.stage_bytes >> 10);
   auto fetch = [&](int c_lo, int c_hi, int last) {
     for (int c = c_lo; c < c_hi; ++c) {
       const int piece = min(lane + 64 * c, last);
       dma16(rec + (int64_t)piece * 16, stage_lds + 1024u * (uint32_t)c);
     }
   };
-  fetch(0, n_dma_first, (cv.rec_bytes >> 4) - 1);
+  fetch(0, 1, (cv.rec_bytes >> 4) - 1);
 
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
@@ -434,6 +442,10 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       }
     }
     const int n_listed = min(n_cards, R);
+    {  // second part of the record
+      const int need_pieces = min((cv.off_cards >> 4) + n_listed, cv.rec_bytes >> 4);
+      fetch(1, (need_pieces + 63) >> 6, need_pieces - 1);
+    }
 
     // obs:global_ (:1605-1620), eight bytes built as two wave-uniform words: lp of to_play and of
     // the opponent (float_transform: high byte, low byte), phase id, "I am player 0", "it is my
@@ -464,14 +476,6 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       // ---- A: the landing area is complete ----
       vm_wait<0>();
       wave_fence();
-      {  // second part of the record: listed cards beyond what the first fetch covered (if any)
-        const int need_pieces = (cv.off_cards >> 4) + n_listed;
-        if (NIT > 1 && need_pieces > n_dma_first * 64) {
-          fetch(n_dma_first, (need_pieces + 63) >> 6, need_pieces - 1);
-          vm_wait<0>();
-          wave_fence();
-        }
-      }
       const int last_card = max(n_listed, 1) - 1;  // lanes without a card re-read the last listed one
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
 #pragma unroll
-        for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = d < 3 + a.mms ? src[d] : 0u;
+        for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = src[d];  // (past 3 + mms: in-bounds bytes nobody uses)
       }
       // obs:h_actions_ is the ring rotated so that the newest entry is row 0 (:1881-1892): image
       // row i = ring row (i + ha_p) mod n_history_actions. One lane per row, copied now (the
@@ -580,19 +584,27 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
         KArgs ka = late_args();
         const bool done = (w[1] >> 24) != 0;
         const int elapsed = (int)w[3];
-        ka->out.env_id[e] = (int)w[2];
-        ka->out.penv[e] = (int)w[2];
-        ka->out.elapsed[e] = elapsed;
-        ka->out.done[e] = done;
-        ka->out.reward[e] = __uint_as_float(w[8]);
-        ka->out.discount[e] = done ? 0.f : 1.f;
-        ka->out.step_type[e] = elapsed == 0 ? 0 : (done ? 2 : 1);
-        ka->out.trunc[e] = done && (elapsed >= ka->max_episode_steps);
-        ka->out.num_options[e] = no_options ? 1 : n_opt;
-        ka->out.to_play[e] = to_play;
-        ka->out.is_selfplay[e] = (int)(w[1] & 0xff);
-        ka->out.win_reason[e] = (int)w[7];
-        *reinterpret_cast<uint2*>(ka->out.global + e * 8) = make_uint2(glob0, glob1);
+        // (one 32-bit lane offset per element width, added to the wave-uniform array bases by the
+        // store instruction itself: e < 2^29)
+        uint32_t ev = (uint32_t)e;
+        asm volatile("" : "+v"(ev));
+        const uint32_t o4 = ev << 2, o8 = ev << 3;
+        auto put = [](auto* base, uint32_t off, auto v) {
+          *reinterpret_cast<decltype(v)*>(reinterpret_cast<char*>(base) + off) = v;
+        };
+        put(ka->out.env_id, o4, (int)w[2]);
+        put(ka->out.penv, o4, (int)w[2]);
+        put(ka->out.elapsed, o4, elapsed);
+        put(ka->out.done, ev, (uint8_t)done);
+        put(ka->out.reward, o4, __uint_as_float(w[8]));
+        put(ka->out.discount, o4, done ? 0.f : 1.f);
+        put(ka->out.step_type, o4, elapsed == 0 ? 0 : (done ? 2 : 1));
+        put(ka->out.trunc, ev, (uint8_t)(done && (elapsed >= ka->max_episode_steps)));
+        put(ka->out.num_options, o4, no_options ? 1 : n_opt);
+        put(ka->out.to_play, o4, to_play);
+        put(ka->out.is_selfplay, o4, (int)(w[1] & 0xff));
+        put(ka->out.win_reason, o4, (int)w[7]);
+        put(ka->out.global, o8, make_uint2(glob0, glob1));
       }
 
 
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
             const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
             const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
             const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
-            if (ti >= 0) my_spec[ti] = (uint8_t)(r + 1);
+            if (ti >= 0) my_spec[YGO_SPEC_IX(ti)] = (uint8_t)(r + 1);
             ti_of[it] = ti;
             row1_of[it] = (uint32_t)(r + 1) & 0xff;
             key_of[it] = ti >= 0 ? (uint32_t)ti : 0x80000000u | pi | (loc7 << 1) | (seq << 8) | (suf << 16);
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
       bool dup = false;
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[ti_of[it]] != row1_of[it]) dup = true;
+        if (ti_of[it] >= 0 && !(YGO_SKIP & 2) && my_spec[YGO_SPEC_IX(ti_of[it])] != row1_of[it]) dup = true;
       dup = __any(dup);
       // ---- obs:actions_ (:1674-1765) + h_card_ids (:1863-1879): lane i owns option i ----
 #pragma unroll
@@ -700,7 +712,7 @@ __global__ __launch_bounds__(kThreads, 5) void ygo_encode(Args a) {
             const uint32_t key = mw[3 + j];  // spec reference: a table slot, or bit 31 | the spec
             const bool fast = act & (key < (uint32_t)spec_slots(a.max_cards)) & !dup;
             int idx = 0;
-            if (fast) idx = my_spec[key];
+            if (fast) idx = my_spec[YGO_SPEC_IX(key)];
             // A key outside the direct-mapped table, or an env with two rows under one spec: the
             // exact search, last row wins (:1549). Rare; done by the whole wave for one option at a
             // time - every lane compares the key with the cards it owns, then a wave-wide maximum.
