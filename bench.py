@@ -276,7 +276,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": big["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": big["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None, "kernel": "ygo_encode",
                      "kernel_us": big["kernel_us"], "alg_bytes_per_record": big["alg_bytes_per_record"]},
-        "config3_us_per_step": c3["us_per_step_wall"], "config3_kernel_us": c3["kernel_us"],
+        "value_config3_in_place_pcie_inclusive": c3["encodes_per_s_in_place_pcie_inclusive"],
+        "config3_us_per_step": c3["us_per_step_wall"], "config3_us_per_step_in_place": c3["us_per_step_wall_in_place"],
+        "config3_kernel_us": c3["kernel_us"], "config3_zero_copy": c3.get("zero_copy"),
+        "config3_staging_copy_us": c3["h2d_copy_us"],
         "host_emit_records_per_s_1core": r["host_emit_records_per_s_1core"],
       }
       if "cpu_oracle_encodes_per_s_1core" in r:

@@ -83,6 +83,7 @@ struct ep_ygo_encoder {
   std::mutex mu;
   std::shared_ptr<epc::HostBlocks> blocks;
   bool timing = false;
+  bool zero_copy = true;  // the kernel reads the pinned slot over PCIe itself (no staging copy); EP_YGO_ZERO_COPY=0: stage through d_rec
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
   double timed_total_us = 0;
   int64_t timed_launches = 0;
@@ -110,7 +111,8 @@ void out_ptrs(ep_ygo_encoder* e, char* base, ygk::Outs* o) {
   o->h_card_ids = (uint16_t*)(base + e->key_off[16]);
 }
 
-int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
+int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot, bool lean_fetch = false, hipStream_t st = nullptr) {
+  if (!st) st = e->stream;
   ygk::Args a;
   a.records = (const uint8_t*)d_records;
   a.stride = e->lay.stride;
@@ -125,6 +127,7 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
   a.mms = e->cfg.max_multi_select;
   a.nf = e->lay.nf;
   a.max_episode_steps = e->cfg.max_episode_steps;
+  a.lean_fetch = lean_fetch ? 1 : 0;
   a.cv = ygk::carve(e->cfg.max_cards, e->cfg.max_options, e->cfg.n_history_actions, e->cfg.max_multi_select);
   out_ptrs(e, e->slots[slot].d_out, &a.out);
   a.err = e->d_err + slot;
@@ -133,13 +136,13 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot) {
   if (e->timing) {
     HIP_TRY(hipEventCreate(&t0));
     HIP_TRY(hipEventCreate(&t1));
-    HIP_TRY(hipEventRecord(t0, e->stream));
+    HIP_TRY(hipEventRecord(t0, st));
   }
   const int groups = (n + ygk::kGroup - 1) / ygk::kGroup;
-  hipLaunchKernelGGL(ygk::ygo_encode, dim3(groups), dim3(ygk::kThreads), e->lds_bytes, e->stream, a);
+  hipLaunchKernelGGL(ygk::ygo_encode, dim3(groups), dim3(ygk::kThreads), e->lds_bytes, st, a);
   HIP_TRY(hipGetLastError());
   if (e->timing) {
-    HIP_TRY(hipEventRecord(t1, e->stream));
+    HIP_TRY(hipEventRecord(t1, st));
     e->timed.emplace_back(t0, t1);
   }
   return EP_OK;
@@ -236,8 +239,9 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   }
   e->out_bytes = off;
   e->slots.resize(e->cfg.ring_depth);
+  if (const char* z = getenv("EP_YGO_ZERO_COPY")) e->zero_copy = atoi(z) != 0;
   for (auto& s : e->slots) {
-    HIP_TRY(hipHostMalloc((void**)&s.h_rec, (size_t)e->lay.stride * B, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&s.h_rec, (size_t)e->lay.stride * B, hipHostMallocMapped));
     HIP_TRY(hipMalloc((void**)&s.d_rec, (size_t)e->lay.stride * B));
     HIP_TRY(hipMalloc((void**)&s.d_out, e->out_bytes));
     HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
@@ -391,16 +395,29 @@ int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {
   const int si = (int)(e->submit_idx % e->slots.size());
   Slot& s = e->slots[si];
   s.n = n;
+  hipStream_t st = e->stream;
   if (n > 0) {
-    // side-stream copy; the compute stream only waits for THIS batch's copy, so the copy of
-    // batch k+1 runs under the kernel of batch k
-    HIP_TRY(hipMemcpyAsync(s.d_rec, s.h_rec, (size_t)n * e->lay.stride, hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
-    int rc = launch(e, s.d_rec, n, si);
+    int rc;
+    if (e->zero_copy) {
+      // the kernel fetches each record's USED part straight from the pinned slot (it is
+      // device-mapped): less PCIe traffic than copying whole fixed-stride records, and no copy
+      // step. Consecutive batches alternate between two streams, so the PCIe round trips at the
+      // head and tail of one kernel run under the bulk of its neighbour.
+      void* dev_view = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev_view, s.h_rec, 0));
+      st = (e->submit_idx & 1) ? e->copy_stream : e->stream;
+      rc = launch(e, (const char*)dev_view, n, si, /*lean_fetch=*/true, st);
+    } else {
+      // side-stream copy; the compute stream only waits for THIS batch's copy, so the copy of
+      // batch k+1 runs under the kernel of batch k
+      HIP_TRY(hipMemcpyAsync(s.d_rec, s.h_rec, (size_t)n * e->lay.stride, hipMemcpyHostToDevice, e->copy_stream));
+      HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+      HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+      rc = launch(e, s.d_rec, n, si);
+    }
     if (rc) return rc;
   }
-  HIP_TRY(hipEventRecord(s.done, e->stream));
+  HIP_TRY(hipEventRecord(s.done, st));
   s.busy = true;
   e->submit_idx++;
   return EP_OK;

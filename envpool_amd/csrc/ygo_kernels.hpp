@@ -64,7 +64,7 @@ struct Carve {
   int cards, actions, hact, global, hcids, spec, stage, wave_stride, total, spec_stride;
   int zero_bytes;                               // [cards, spec end) starts every env as zeros
   int off_hist, off_cards, off_opts, rec_bytes; // record layout (include/envpool_amd_ygo.h)
-  int stage_bytes;                              // rec_bytes rounded up to whole 1 KiB LDS-DMA instructions
+  int stage_bytes;                              // landing area of the record in LDS (whole 1 KiB LDS-DMA instructions per span)
 };
 // direct-mapped spec table of one env: [2 players][7 locations][max_cards sequences] plus
 // [2][8 monster zones][8 overlay letters], one byte each (1-based row index, 0 = absent)
@@ -83,7 +83,11 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   c.off_opts = c.off_hist + al16(n_hist * nf);
   c.off_cards = al16(c.off_opts + max_options * option_bytes(mms));
   c.rec_bytes = al16(c.off_cards + R * (int)sizeof(ygo_card));
-  c.stage_bytes = (c.rec_bytes + 1023) & ~1023;
+  // every LDS-DMA instruction writes a whole KiB (lanes past the end of a span repeat its last
+  // piece): the landing area reaches to where the last instruction of either span can write
+  c.stage_bytes = max(max(c.off_hist + ((c.off_cards - c.off_hist + 1023) & ~1023),
+                          c.off_cards + ((R * (int)sizeof(ygo_card) + 1023) & ~1023)),
+                      (c.rec_bytes + 1023) & ~1023);
   int o = 0;
   c.cards = o;   o += max(al16(R * 39) + 16, c.stage_bytes);  // doubles as the record's landing area
   c.actions = o; o += al16(max_options * nf) + 16;
@@ -111,6 +115,7 @@ struct Args {
   uint32_t table_mask;  // capacity - 1
   uint32_t table_mul_b; // multiplier of the second hash function (chosen by the host build)
   int32_t max_cards, max_options, n_hist, mms, nf, max_episode_steps;
+  int32_t lean_fetch;  // 1: records in pinned host memory, fetch schedule for PCIe (ygo_encode)
   Carve cv;  // LDS arena and record layout, computed once on the host
   Outs out;
   uint32_t* err;  // host-mapped error word of this batch
@@ -289,18 +294,22 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
   uint8_t* const my_spec = lds + arena + cv.spec;
   const uint8_t* const stage = lds + arena + cv.stage;
   const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage);
-  // The record is fetched in two parts: its first KiB at once (one DMA instruction), the rest up
-  // to the last LISTED card once the header (scalar loads, below) has told how many there are -
-  // the unused tail of the card array never leaves HBM. `last` is the last 16-byte piece wanted:
-  // lanes past it re-read it (same cache line, no extra traffic).
+  // Only the used part of a record is fetched, by LDS-DMA in 16-byte pieces (lanes past the last
+  // piece of a span re-read it: same cache line, no extra traffic). Two schedules, chosen by the
+  // host per launch:
+  //   records in HBM: the first KiB at once, in parallel with the header's scalar loads (below),
+  //     the rest up to the last listed card once the header has told how many there are;
+  //   records in pinned host memory (the kernel reads them over PCIe itself, a.lean_fetch): nothing
+  //     before the header; then exactly the history ring with the used options, and the listed
+  //     cards, each span to its own place in the landing area - every byte saved is PCIe time.
   const uint8_t* const rec = a.records + e * a.stride;
-  auto fetch = [&](int c_lo, int c_hi, int last) {
-    for (int c = c_lo; c < c_hi; ++c) {
-      const int piece = min(lane + 64 * c, last);
-      dma16(rec + (int64_t)piece * 16, stage_lds + 1024u * (uint32_t)c);
+  auto fetch_span = [&](int first_piece, int n_pieces, int c_lo) {  // pieces [first, first + n) -> stage + 16*first
+    for (int c = c_lo; 64 * c < n_pieces; ++c) {
+      const int piece = first_piece + min(lane + 64 * c, n_pieces - 1);
+      dma16(rec + (int64_t)piece * 16, stage_lds + 16u * (uint32_t)first_piece + 1024u * (uint32_t)c);
     }
   };
-  fetch(0, 1, (cv.rec_bytes >> 4) - 1);
+  if (!a.lean_fetch) fetch_span(0, 64, 0);
 
   // the images of one env leave the CU: aligned 16-byte-per-lane stores for the bulk
   auto flush_env = [&](int64_t env, int lane) {
@@ -442,9 +451,12 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
       }
     }
     const int n_listed = min(n_cards, R);
-    {  // second part of the record
-      const int need_pieces = min((cv.off_cards >> 4) + n_listed, cv.rec_bytes >> 4);
-      fetch(1, (need_pieces + 63) >> 6, need_pieces - 1);
+    if (!a.lean_fetch) {
+      fetch_span(0, min((cv.off_cards >> 4) + n_listed, cv.rec_bytes >> 4), 1);
+    } else if (!no_options) {
+      const int used_opts_end = (cv.off_opts + n_opt * option_bytes(a.mms) + 15) >> 4;
+      fetch_span(cv.off_hist >> 4, used_opts_end - (cv.off_hist >> 4), 0);
+      fetch_span(cv.off_cards >> 4, n_listed, 0);
     }
 
     // obs:global_ (:1605-1620), eight bytes built as two wave-uniform words: lp of to_play and of
