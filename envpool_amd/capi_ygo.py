@@ -50,7 +50,7 @@ SYMBOLS = [
   "ep_ygo_encoder_create", "ep_ygo_encoder_destroy", "ep_ygo_set_card_table", "ep_ygo_record_stride",
   "ep_ygo_action_feats", "ep_ygo_featurize", "ep_ygo_submit", "ep_ygo_collect", "ep_ygo_acquire_slot",
   "ep_ygo_commit_slot", "ep_ygo_sync", "ep_ygo_stream", "ep_ygo_set_timing", "ep_ygo_kernel_time_us",
-  "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push",
+  "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy",
 ]
 
 _bound = None
@@ -77,6 +77,7 @@ def lib():
     L.ep_ygo_stream.argtypes = [vp]
     L.ep_ygo_stream.restype = vp
     L.ep_ygo_set_timing.argtypes = [vp, i32]
+    L.ep_ygo_set_zero_copy.argtypes = [vp, i32]
     L.ep_ygo_kernel_time_us.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), i32]
     L.ep_ygo_emit_record.argtypes = [C.POINTER(YgoConfig), C.POINTER(RawState), vp]
     L.ep_ygo_emit_records.argtypes = [C.POINTER(YgoConfig), C.POINTER(RawState), i32, vp, vp]

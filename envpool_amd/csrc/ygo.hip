@@ -492,6 +492,14 @@ int ep_ygo_sync(ep_ygo_encoder* e) {
 
 void* ep_ygo_stream(ep_ygo_encoder* e) { return e ? (void*)e->stream : nullptr; }
 
+int ep_ygo_set_zero_copy(ep_ygo_encoder* e, int32_t enabled) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->submit_idx != e->collect_idx) return fail(EP_ERR_INVALID, "batches in flight: collect them first");
+  e->zero_copy = enabled != 0;
+  return EP_OK;
+}
+
 int ep_ygo_set_timing(ep_ygo_encoder* e, int32_t enabled) {
   if (!e) return fail(EP_ERR_INVALID, "null encoder");
   e->timing = enabled != 0;

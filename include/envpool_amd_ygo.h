@@ -159,6 +159,14 @@ int ep_ygo_collect(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);
  * place (no memcpy): acquire -> fill n records -> commit. */
 int ep_ygo_acquire_slot(ep_ygo_encoder* enc, void** pinned_records);
 int ep_ygo_commit_slot(ep_ygo_encoder* enc, int32_t n);
+/* How a committed slot reaches the kernel. enabled != 0 (the default; EP_YGO_ZERO_COPY=0 in the
+ * environment changes the default): the kernel reads the USED part of every record straight from
+ * the pinned slot over PCIe - no staging copy, about half the PCIe bytes of a fixed-stride copy;
+ * consecutive batches alternate between two streams. enabled == 0: the slot is first copied to
+ * device memory on a side stream (whole records), under the kernel of the batch before. Results
+ * are identical. Call with no batch in flight. No counterpart in the reference (its records never
+ * leave the host). */
+int ep_ygo_set_zero_copy(ep_ygo_encoder* enc, int32_t enabled);
 int ep_ygo_sync(ep_ygo_encoder* enc);
 void* ep_ygo_stream(ep_ygo_encoder* enc);
 int ep_ygo_set_timing(ep_ygo_encoder* enc, int32_t enabled);

@@ -150,9 +150,11 @@ def test_exact_spec_search_paths():
   enc.close()
 
 
-def test_submit_collect_pipeline_and_device_records():
-  """Several batches in flight (pinned staging + side-stream copy), results in FIFO order;
-  device-resident records give the same bytes."""
+@pytest.mark.parametrize("zero_copy", [1, 0])
+def test_submit_collect_pipeline_and_device_records(zero_copy):
+  """Several batches in flight, results in FIFO order, both ways a pinned slot reaches the kernel
+  (read in place over PCIe / staged by a side-stream copy); device-resident records give the same
+  bytes."""
   import torch
   from oracle import ygo_oracle
   from tools import ygo_synth
@@ -160,6 +162,7 @@ def test_submit_collect_pipeline_and_device_records():
   table = ygo_synth.make_table(500, seed=9)
   enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
   L = capi_ygo.lib()
+  assert L.ep_ygo_set_zero_copy(enc.handle, zero_copy) == 0
   batches = []
   for b in range(7):
     n = [256, 100, 8, 255, 1, 64, 200][b]
@@ -176,6 +179,8 @@ def test_submit_collect_pipeline_and_device_records():
       w, o = pending.pop(0)
       _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), w, o, "pipelined")
     enc.submit(recs)
+    if len(pending) == 0:
+      assert L.ep_ygo_set_zero_copy(enc.handle, zero_copy) == capi.EP_ERR_INVALID  # a batch is in flight
     pending.append((want, ok))
   while pending:
     w, o = pending.pop(0)
