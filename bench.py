@@ -200,6 +200,22 @@ def main():
       "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
       "note": "ep_pool_send + blocking ep_pool_recv per lockstep step, device-resident actions",
     }
+    # the same loop with the stream-ordered recv: batches are handed out as device views on the
+    # pool's own stream (where a GPU-resident policy would run), the host never waits per step
+    for _ in range(16):
+      check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv_on_stream(h, None, C.byref(batch)))
+    check(L.ep_pool_sync(h))
+    kso = 4 * ks
+    s0 = time.perf_counter()
+    for _ in range(kso):
+      check(L.ep_pool_send(h, 5, p1, dims, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv_on_stream(h, None, C.byref(batch)))
+    check(L.ep_pool_sync(h))
+    s1 = time.perf_counter()
+    per_step["stream_ordered"] = {
+      "value": N * kso / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / kso * 1e3,
+      "note": "ep_pool_send + ep_pool_recv_on_stream per lockstep step (no host wait inside the loop)"}
 
   # the boundary also takes host buffers (the reference's numpy path): PCIe-inclusive rate,
   # host actions in, host StateBuffer out, one launch per step. Reported, never `value`.

@@ -37,7 +37,7 @@ class Batch(C.Structure):
 
 SYMBOLS = [
   "ep_dummy_pool_create", "ep_pool_destroy", "ep_pool_reset", "ep_pool_send", "ep_pool_recv",
-  "ep_pool_recv_many", "ep_pool_episode_stats_async",
+  "ep_pool_recv_many", "ep_pool_recv_on_stream", "ep_pool_episode_stats_async",
   "ep_batch_release", "ep_pool_rollout", "ep_pool_sync", "ep_pool_episode_stats",
   "ep_pool_checkpoint_bytes", "ep_pool_checkpoint_save", "ep_pool_checkpoint_restore",
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
@@ -59,6 +59,7 @@ def lib():
     L.ep_pool_send.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64), i32]
     L.ep_pool_recv.argtypes = [vp, i32, C.POINTER(Batch)]
     L.ep_pool_recv_many.argtypes = [vp, i32, i32, C.POINTER(Batch)]
+    L.ep_pool_recv_on_stream.argtypes = [vp, vp, C.POINTER(Batch)]
     L.ep_pool_episode_stats_async.argtypes = [vp, vp, vp, vp, vp]
     L.ep_batch_release.argtypes = [C.POINTER(Batch)]
     L.ep_pool_rollout.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]

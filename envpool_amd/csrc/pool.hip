@@ -88,7 +88,8 @@ struct ep_pool {
   std::vector<hipEvent_t> done_ev_pool;
   uint64_t launch_seq = 0;       // launches enqueued on `stream`
   uint64_t completed_launch = 0; // highest launch id known to have finished (stream is in-order)
-  hipEvent_t stats_ev = nullptr, consumer_ev = nullptr;
+  hipEvent_t stats_ev = nullptr, consumer_ev = nullptr, recv_ev = nullptr;
+  std::vector<uint8_t> deferred_err;  // [Q] slots handed out by ep_pool_recv_on_stream, error word not looked at yet
   std::vector<SlotHost> slots;
   std::mutex mu;
   std::shared_ptr<HostBlocks> blocks;
@@ -449,6 +450,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->slots.resize(p->Q);
   HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->recv_ev, hipEventDisableTiming));
+  p->deferred_err.assign((size_t)p->Q, 0);
   p->blocks = std::make_shared<HostBlocks>();
   p->blocks->bytes = p->slot_stride;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -467,6 +470,7 @@ int ep_pool_destroy(ep_pool* p) {
   for (auto e : p->done_ev_pool) (void)hipEventDestroy(e);
   if (p->stats_ev) (void)hipEventDestroy(p->stats_ev);
   if (p->consumer_ev) (void)hipEventDestroy(p->consumer_ev);
+  if (p->recv_ev) (void)hipEventDestroy(p->recv_ev);
   for (auto e : p->stage_free) (void)hipEventDestroy(e);
   for (auto e : p->stage_copied) (void)hipEventDestroy(e);
   (void)hipFree(p->d_ring);
@@ -634,7 +638,9 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
 }  // extern "C"
 
 namespace {
-int recv_locked(ep_pool* p, int32_t mem, ep_batch* out) {
+// `consumer` != nullptr: stream-ordered form (ep_pool_recv_on_stream) - device views at once, the
+// consumer stream is made to wait instead of the host.
+int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = nullptr) {
   int rc = EP_OK;
   const int slot = (int)(p->done_ptr % (uint64_t)p->Q);
   SlotHost& sh = p->slots[slot];
@@ -648,7 +654,10 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out) {
                 (unsigned long long)sh.alloc_count, p->B);
   const uint32_t nrows = sh.shared_off;
   uint32_t nplayers = nrows;
-  if (sh.has_work)
+  if (consumer && p->P > 1)
+    return fail(EP_ERR_INVALID, "ep_pool_recv_on_stream needs max_num_players == 1 (the player row count of a "
+                                "multi-player batch is only known on the device)");
+  if (sh.has_work && !consumer)
     if ((rc = wait_launch(p, sh.launch_id))) return rc;
   if (p->P > 1) {
     HIP_TRY(hipMemcpyAsync(p->h_slot_players + slot, p->d_slot_players + slot, 4, hipMemcpyDeviceToHost, p->stream));
@@ -677,18 +686,38 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out) {
     }
     if (cur < (int64_t)nrows)
       if ((rc = zero_rows(cur, nrows))) return rc;
-    if (any) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (any && !consumer) HIP_TRY(hipStreamSynchronize(p->stream));
   }
   int status = EP_OK;
-  if (p->h_err[slot].action_check) {
+  if (consumer) {
+    // everything this batch needs is already on the step stream: another stream waits for it
+    // there, the step stream itself is in order anyway. The slot's error word is looked at later
+    // (ep_pool_sync), when the kernels have run.
+    if (*consumer != p->stream) {
+      HIP_TRY(hipEventRecord(p->recv_ev, p->stream));
+      HIP_TRY(hipStreamWaitEvent(*consumer, p->recv_ev, 0));
+    }
+    p->deferred_err[slot] = 1;
+    // nobody waits for launches on the host in this mode: retire their completion events here,
+    // which also keeps the host from running more than about two rings ahead of the device
+    while (p->inflight.size() > (size_t)(2 * p->Q + 8)) {
+      HIP_TRY(hipEventSynchronize(p->inflight.front().second));
+      p->completed_launch = std::max(p->completed_launch, p->inflight.front().first);
+      p->done_ev_pool.push_back(p->inflight.front().second);
+      p->inflight.pop_front();
+    }
+  } else if (p->h_err[slot].action_check) {
     status = fail(EP_ERR_ACTION_CHECK,
                   "Dummy action self-check failed: list_action lanes differ (the reference aborts "
                   "here, dummy_envpool.h:189-192)");
   } else if (p->h_err[slot].env_id_range) {
     status = fail(EP_ERR_ACTION_CHECK, "an env_id in the sent batch is outside this pool's shard");
   }
-  p->h_err[slot].action_check = 0;
-  p->h_err[slot].env_id_range = 0;
+  if (!consumer) {
+    p->h_err[slot].action_check = 0;
+    p->h_err[slot].env_id_range = 0;
+    p->deferred_err[slot] = 0;
+  }
 
   memset(out, 0, sizeof(*out));
   out->num_keys = 12;
@@ -753,6 +782,15 @@ int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
   return recv_locked(p, mem, out);
 }
 
+int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : p->stream;
+  return recv_locked(p, EP_MEM_DEVICE, out, &cs);
+}
+
 int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
   std::lock_guard<std::mutex> lk(p->mu);
@@ -805,6 +843,18 @@ int ep_pool_sync(ep_pool* p) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(p->copy_stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  // batches handed out by ep_pool_recv_on_stream: their error words are final now
+  bool bad = false;
+  for (int s = 0; s < p->Q; ++s) {
+    if (!p->deferred_err[s]) continue;
+    p->deferred_err[s] = 0;
+    if (p->h_err[s].action_check || p->h_err[s].env_id_range) bad = true;
+    p->h_err[s].action_check = 0;
+    p->h_err[s].env_id_range = 0;
+  }
+  if (bad)
+    return fail(EP_ERR_ACTION_CHECK, "a batch received with ep_pool_recv_on_stream failed the Dummy action self-check "
+                                     "or carried an env_id outside this pool's shard");
   return EP_OK;
 }
 

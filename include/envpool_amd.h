@@ -144,6 +144,19 @@ int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
  * env's action self-check (the batch is still returned). */
 int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
 
+/* Stream-ordered ep_pool_recv(EP_MEM_DEVICE): describes the head batch as device views at once
+ * and makes `consumer_stream` (a hipStream_t; NULL or ep_pool_stream() = the pool's own step
+ * stream, which needs no wait at all) wait for the kernels that write it - the host never
+ * blocks, so a policy that runs on the GPU sees one kernel launch per step instead of a launch
+ * plus a host round trip. Same EP_ERR_WOULD_BLOCK rule as ep_pool_recv. Differences: single-player
+ * pools only (EP_ERR_INVALID otherwise); an action self-check failure of such a batch is reported
+ * by the next ep_pool_sync, not here; the views stay valid until ring_depth-1 further batches
+ * have been received AND the consumer's reads are ordered before the step stream's later work
+ * (automatic when the consumer is the step stream; the library lets the host run at most about
+ * two rings ahead). No counterpart in the reference (StateBufferQueue::Wait always blocks a host
+ * thread, state_buffer_queue.h:139-150). */
+int ep_pool_recv_on_stream(ep_pool* pool, void* consumer_stream, ep_batch* out);
+
 /* `n` consecutive ep_pool_recv calls in one (the natural companion of
  * ep_pool_rollout). `out` points at n ep_batch structs. */
 int ep_pool_recv_many(ep_pool* pool, int32_t mem, int32_t n, ep_batch* out);

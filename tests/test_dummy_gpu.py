@@ -281,3 +281,62 @@ def test_checkpoint_roundtrip():
   capi._check(L.ep_pool_checkpoint_restore(g.handle, buf))
   for w in want:
     g._send(dummy_action(ids)); assert_batches_equal(g._recv(), w, "after restore")
+
+
+def test_recv_on_stream_policy_loop():
+  """ep_pool_recv_on_stream: a GPU-resident policy (torch, running ON the pool's step stream) reads
+  each batch as device views and sends actions computed from it; the host never waits inside the
+  loop. Every step against the oracle driven by the same policy in numpy."""
+  import ctypes as C
+
+  import torch
+
+  from envpool_amd import capi, interop
+
+  n, T = 4096, 40
+  g, o = _pair(num_envs=n, seed=7, ring_depth=4)   # far fewer slots than steps: the views are consumed in order
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  t_ids = torch.from_numpy(ids).to(dev)
+  t_z = torch.zeros(n, dtype=torch.int32, device=dev)
+  t_penv = torch.empty(n, dtype=torch.int32, device=dev)
+  t_la = torch.empty((n, 6), dtype=torch.float64, device=dev)
+  torch.cuda.synchronize()
+  ext = torch.cuda.ExternalStream(L.ep_pool_stream(g.handle))
+  ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_penv.data_ptr(), t_la.data_ptr(), t_z.data_ptr(), t_z.data_ptr())
+  dims = (C.c_int64 * 5)(n, n, n, n, n)
+  b = capi.Batch()
+  logged = []
+
+  def view(k):
+    a = b.arrays[k]
+    shape = tuple(a.shape[i] for i in range(a.ndim))
+    return interop.as_torch((a.data, shape, np.dtype(capi._NP[a.dtype]).str), device=dev)
+
+  with torch.cuda.stream(ext):
+    for t in range(T):
+      capi._check(L.ep_pool_recv_on_stream(g.handle, None, C.byref(b)))
+      assert b.num_rows == n
+      elapsed, raw = view(2), view(8)
+      logged.append([view(k).clone() for k in range(b.num_keys) if b.arrays[k].dtype != capi.EP_CONTAINER_I32])
+      t_penv.copy_(t_ids + (elapsed % 3 == 0).to(torch.int32))   # a mismatch on some rows
+      t_la.copy_(((elapsed + raw[:, 0]) % 5).to(torch.float64).unsqueeze(1).expand(n, 6))
+      capi._check(L.ep_pool_send(g.handle, 5, ptrs, dims, capi.EP_MEM_DEVICE))
+  capi._check(L.ep_pool_sync(g.handle))
+  fixed = [k for k in range(b.num_keys) if b.arrays[k].dtype != capi.EP_CONTAINER_I32]
+  for t in range(T):
+    want = o._recv()
+    for j, k in enumerate(fixed):
+      got = logged[t][j].cpu().numpy()
+      assert got.tobytes() == np.asarray(want[k]).tobytes(), f"t={t} key {k}"
+    el, rw = np.asarray(want[2]), np.asarray(want[8])
+    la = np.repeat(((el + rw[:, 0]) % 5).astype(np.float64)[:, None], 6, axis=1)
+    o._send([ids, ids + (el % 3 == 0).astype(np.int32), la, np.zeros(n, np.int32), np.zeros(n, np.int32)])
+  # the batch of the last send is still outstanding: the blocking form drains it
+  assert_batches_equal(g._recv(), o._recv(), "drain")
+  # multi-player pools cannot be received this way
+  g2, _ = _pair(num_envs=8, seed=1, max_num_players=2)
+  g2._reset(np.arange(8, dtype=np.int32))
+  assert L.ep_pool_recv_on_stream(g2.handle, None, C.byref(b)) == capi.EP_ERR_INVALID
