@@ -193,6 +193,20 @@ struct DummyPool {
     return py::make_tuple(out, b.num_rows, b.num_player_rows);
   }
 
+  // Stream-ordered form (ep_pool_recv_on_stream): the same descriptors at once; `stream` (a
+  // hipStream_t as an integer, 0 = the pool's own step stream, _stream()) is made to wait for
+  // the kernels that write the batch instead of the host.
+  py::tuple recv_on_stream(uintptr_t stream) {
+    ep_batch b;
+    epy::check(ep_pool_recv_on_stream(pool, reinterpret_cast<void*>(stream), &b));
+    py::list out;
+    for (int k = 0; k < b.num_keys; ++k) {
+      if (b.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
+      else out.append(epy::device_desc(b.arrays[k]));
+    }
+    return py::make_tuple(out, b.num_rows, b.num_player_rows);
+  }
+
   void send_device(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims) {
     if (ptrs.size() != 5 || dims.size() != 5) throw std::invalid_argument("need 5 pointers and 5 dims");
     const void* p[5];
@@ -271,6 +285,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
       // additive (no reference counterpart)
       .def("_recv_device", &DummyPool::recv_device)
+      .def("_recv_on_stream", &DummyPool::recv_on_stream, py::arg("stream") = 0)
       .def("_send_device", &DummyPool::send_device)
       .def("_rollout", &DummyPool::rollout)
       .def("_episode_stats", &DummyPool::episode_stats)

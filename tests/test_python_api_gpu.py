@@ -98,3 +98,16 @@ def test_device_views_and_torch_interop():
     assert_batches_equal(got, w, f"t={t}")
     pool._send_device([t_ids.data_ptr(), t_ids.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr()], [n] * 5)
     o._send(dummy_action(ids))
+
+  # the stream-ordered form: torch works on the pool's step stream, nothing waits on the host
+  ext = torch.cuda.ExternalStream(pool._stream())
+  kept = []
+  with torch.cuda.stream(ext):
+    for t in range(10):
+      descs, rows, prows = pool._recv_on_stream()
+      kept.append([None if d is None else as_torch(d, dev).clone() for d in descs])
+      pool._send_device([t_ids.data_ptr(), t_ids.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr()], [n] * 5)
+  pool._sync()
+  for t in range(10):
+    assert_batches_equal([None if x is None else x.cpu().numpy() for x in kept[t]], o._recv(), f"on stream t={t}")
+    o._send(dummy_action(ids))
