@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -601,7 +602,7 @@ int parse_location(const uint8_t* buf, int len, std::vector<ygo_card>* out) {
 
 // spec string ("oh3", "m2", "x1", "12", "m3a") -> key; mirrors spec_to_ls (:367-400) but keeps
 // the presence of the overlay suffix, which the string comparison of spec2index distinguishes.
-bool spec_key(const std::string& s, uint32_t* key) {
+bool spec_key(std::string_view s, uint32_t* key) {
   size_t i = 0;
   uint32_t opp = 0;
   if (i < s.size() && s[i] == 'o') { opp = 1; ++i; }
@@ -636,7 +637,7 @@ int list_id(const char* list, char c) {
   return p ? (int)(p - list) + 1 : -1;
 }
 
-int place_id(const std::string& s) {  // cmd_place2id (:680-686)
+int place_id(std::string_view s) {  // cmd_place2id (:680-686)
   size_t i = 0;
   int base = 0;
   if (!s.empty() && s[0] == 'o') { base = 15; i = 1; }
@@ -663,20 +664,36 @@ int pos_id_host(int p) {
 
 enum { F_MSG = 0, F_ACT, F_YESNO, F_PHASE, F_CANCEL, F_POSITION, F_OPTION, F_PLACE, F_ATTRIB };
 
+// The spec strings one option references: views into the option string (no allocation on the
+// per-record path). More than the array holds are counted, not kept.
+struct SpecList {
+  std::string_view v[EP_YGO_MAX_SPECS + 1];
+  size_t n = 0;
+  void push_back(std::string_view s) {
+    if (n <= EP_YGO_MAX_SPECS) v[n] = s;
+    ++n;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  std::string_view operator[](size_t i) const { return v[i]; }
+};
+
 // The grammar of _set_obs_action (:1674-1765). `specs` receives the referenced spec strings.
-int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vector<std::string>* specs) {
+// `option_c` is NUL-terminated.
+int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* specs) {
+  const std::string_view option(option_c);
   memset(feats, 0, 9);
   const int mid = msg_id(msg);
   if (mid < 0) return fail(EP_ERR_INVALID, "Unsupported message %d", msg);
   feats[F_MSG] = (uint8_t)mid;
   if (option.empty()) return fail(EP_ERR_INVALID, "empty option string");
   auto need = [&](int id, const char* what) -> int {
-    return id < 0 ? fail(EP_ERR_INVALID, "option '%s': unknown %s", option.c_str(), what) : EP_OK;
+    return id < 0 ? fail(EP_ERR_INVALID, "option '%s': unknown %s", option_c, what) : EP_OK;
   };
-  auto strip_effect = [](std::string* spec) -> uint8_t {
+  auto strip_effect = [](std::string_view* spec) -> uint8_t {
     if (!spec->empty() && isalpha((unsigned char)spec->back())) {
       uint8_t off = (uint8_t)(spec->back() - 'a');
-      spec->pop_back();
+      spec->remove_suffix(1);
       return off;
     }
     return 0;
@@ -688,7 +705,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
         feats[F_PHASE] = (uint8_t)list_id("bme", option[0]);
       } else {
         const char act = option[0];
-        std::string spec = option.size() >= 2 ? option.substr(2) : std::string();
+        std::string_view spec = option.size() >= 2 ? option.substr(2) : std::string_view();
         uint8_t off = 0;
         if (act == 'v') off = strip_effect(&spec);
         if ((rc = need(list_id("trcsmav", act), "act"))) return rc;
@@ -701,7 +718,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
       if (option[0] == 'c') {
         feats[F_CANCEL] = 1;
       } else {
-        std::string spec = option;
+        std::string_view spec = option;
         const uint8_t off = strip_effect(&spec);
         feats[F_ACT] = (uint8_t)(7 + off);  // 'v'
         specs->push_back(spec);
@@ -712,7 +729,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
       size_t start = 0;
       while (start < option.size()) {
         const size_t idx = option.find(' ', start);
-        if (idx == std::string::npos) { specs->push_back(option.substr(start)); break; }
+        if (idx == std::string_view::npos) { specs->push_back(option.substr(start)); break; }
         specs->push_back(option.substr(start, idx - start));
         start = idx + 1;
       }
@@ -731,7 +748,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
       break;
     }
     case 12: {  // MSG_SELECT_EFFECTYN
-      specs->push_back(option.size() >= 2 ? option.substr(2) : std::string());
+      specs->push_back(option.size() >= 2 ? option.substr(2) : std::string_view());
       if ((rc = need(list_id("yn", option[0]), "yes/no"))) return rc;
       feats[F_YESNO] = (uint8_t)list_id("yn", option[0]);
       break;
@@ -747,7 +764,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
       } else {
         if ((rc = need(list_id("trcsmav", option[0]), "act"))) return rc;
         feats[F_ACT] = (uint8_t)list_id("trcsmav", option[0]);
-        specs->push_back(option.size() >= 2 ? option.substr(2) : std::string());
+        specs->push_back(option.size() >= 2 ? option.substr(2) : std::string_view());
       }
       break;
     }
@@ -761,7 +778,7 @@ int parse_option(int msg, const std::string& option, uint8_t feats[9], std::vect
     }
     case 141: {  // MSG_ANNOUNCE_ATTRIB: attribute2id.at(1 << (c - '1'))
       const int sh = option[0] - '1';
-      if (sh < 0 || sh > 6) return fail(EP_ERR_INVALID, "option '%s': unknown attribute", option.c_str());
+      if (sh < 0 || sh > 6) return fail(EP_ERR_INVALID, "option '%s': unknown attribute", option_c);
       feats[F_ATTRIB] = (uint8_t)(sh + 1);
       break;
     }
@@ -814,7 +831,8 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
     memcpy(rec + lay.off_hist, in->history[in->to_play], (size_t)cfg->n_history_actions * lay.nf);
   if (in->n_options == 0) return EP_OK;  // WriteState's early-out reads nothing else (:1837-1841)
 
-  std::vector<ygo_card> cards;
+  static thread_local std::vector<ygo_card> cards;  // (keeps its capacity from record to record)
+  cards.clear();
   for (int pi = 0; pi < 2; ++pi) {
     const int player = (in->to_play + pi) % 2;
     for (int li = 0; li < 7; ++li) {
@@ -843,7 +861,7 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
   for (int i = 0; i < n_opt; ++i) {
     ygo_option_head* oh = (ygo_option_head*)(rec + lay.off_opts + (size_t)i * opt_bytes);
     uint32_t* keys = (uint32_t*)(oh + 1);  // spec references (ygo_kernels.hpp spec_ref)
-    std::vector<std::string> specs;
+    SpecList specs;
     if (!in->options[i]) return fail(EP_ERR_INVALID, "null option string");
     if ((rc = parse_option(in->msg, in->options[i], oh->feats, &specs))) return rc;
     if ((int)specs.size() > cfg->max_multi_select)
@@ -880,7 +898,7 @@ int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, 
   if (!ring || !ha_p || !option) return fail(EP_ERR_INVALID, "null argument");
   const int nf = 9 + 2 * cfg->max_multi_select;
   uint8_t feats[9];
-  std::vector<std::string> specs;
+  SpecList specs;
   if ((rc = parse_option(msg, option, feats, &specs))) return rc;
   // with an empty spec2index the spec columns carry card ids (:1625): CARD/TRIBUTE/SUM write one
   // per card id (:1711-1714), every other spec-bearing option writes card_ids[0]
