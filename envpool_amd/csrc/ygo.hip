@@ -217,7 +217,15 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   e->device = cfg->device_id;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  {
+    // a different priority class puts the second stream on a hardware queue of its own: the two
+    // streams of the zero-copy mode (and the staging copy of the other mode) then really overlap,
+    // however many other streams the process has (HIP spreads equal-priority streams over only a
+    // few hardware queues)
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, hi));
+  }
   const ygk::Carve cv = ygk::carve(cfg->max_cards, cfg->max_options, cfg->n_history_actions, cfg->max_multi_select);
   e->lds_bytes = cv.total;
   if (e->lds_bytes > 160 * 1024) return fail(EP_ERR_TOO_LARGE, "config needs %d bytes of LDS per workgroup (max 163840)", e->lds_bytes);
