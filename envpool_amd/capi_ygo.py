@@ -126,6 +126,16 @@ class YgoEncoderC:
     self.last_status = rc
     return out
 
+  def featurize_device(self, records_ptr: int, n: int, allow=()):
+    """records already in device memory (uint8 [n, stride] at `records_ptr`) -> numpy arrays."""
+    b = capi.Batch()
+    rc = capi._check(self._L.ep_ygo_featurize(self._h, records_ptr, n, capi.EP_MEM_DEVICE, capi.EP_MEM_HOST,
+                                              C.byref(b)), allow=allow)
+    out = capi.batch_to_numpy(b)
+    self._L.ep_batch_release(C.byref(b))
+    self.last_status = rc
+    return out
+
   def submit(self, records: np.ndarray):
     capi._check(self._L.ep_ygo_submit(self._h, records.ctypes.data, records.shape[0]))
 

@@ -67,6 +67,18 @@ def test_synthetic_parity(n, seed, kw):
   # the batch reports "the reference would throw" exactly when the oracle says so for some record
   assert (enc.last_status == capi.EP_ERR_ACTION_CHECK) == bool(((status != 0) & (est == 0)).any())
   _compare(got, want, ok, f"n={n} seed={seed}")
+  # the same records resident in HBM (the other fetch schedule of the kernel) and, for host
+  # records, the staged-copy way to the device: all three give the same bytes
+  if n <= 1000:
+    import torch
+    t = torch.from_numpy(recs.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    got_dev = enc.featurize_device(t.data_ptr(), n, allow=(capi.EP_ERR_ACTION_CHECK,))
+    _compare(got_dev, want, ok, f"device records n={n} seed={seed}")
+    assert capi_ygo.lib().ep_ygo_set_zero_copy(enc.handle, 0) == 0
+    got_staged = enc.featurize(recs, allow=(capi.EP_ERR_ACTION_CHECK,))
+    _compare(got_staged, want, ok, f"staged records n={n} seed={seed}")
+  enc.close()
 
 
 def test_throw_conditions_are_reported():
