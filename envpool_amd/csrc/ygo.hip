@@ -25,7 +25,7 @@ using epc::fail;
 namespace {
 
 struct Layout {  // record layout for one config
-  int nf, off_hist, off_cards, off_opts;
+  int nf, off_hist, off_cards;  // the options follow the record's own cards: off_cards + 16 * n_cards
   int64_t stride;
 };
 
@@ -33,10 +33,9 @@ Layout make_layout(const ep_ygo_config& c) {
   Layout l;
   l.nf = 9 + 2 * c.max_multi_select;
   l.off_hist = 64;
-  l.off_opts = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
-  l.off_cards = l.off_opts + c.max_options * ygk::option_bytes(c.max_multi_select);
-  l.off_cards = (l.off_cards + 15) & ~15;
-  l.stride = (int64_t)align_up((size_t)l.off_cards + (size_t)2 * c.max_cards * sizeof(ygo_card));
+  l.off_cards = l.off_hist + ((c.n_history_actions * l.nf + 15) & ~15);
+  l.stride = (int64_t)align_up((size_t)l.off_cards + (size_t)2 * c.max_cards * sizeof(ygo_card) +
+                               (size_t)c.max_options * ygk::option_bytes(c.max_multi_select));
   return l;
 }
 
@@ -229,7 +228,7 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   const ygk::Carve cv = ygk::carve(cfg->max_cards, cfg->max_options, cfg->n_history_actions, cfg->max_multi_select);
   e->lds_bytes = cv.total;
   if (e->lds_bytes > 160 * 1024) return fail(EP_ERR_TOO_LARGE, "config needs %d bytes of LDS per workgroup (max 163840)", e->lds_bytes);
-  if (cv.off_hist != e->lay.off_hist || cv.off_cards != e->lay.off_cards || cv.off_opts != e->lay.off_opts || cv.rec_bytes > e->lay.stride)
+  if (cv.off_hist != e->lay.off_hist || cv.off_cards != e->lay.off_cards || cv.rec_bytes > e->lay.stride)
     return fail(EP_ERR_INVALID, "internal: kernel and host record layouts disagree");
   // output block layout
   const size_t B = (size_t)cfg->max_batch;
@@ -866,8 +865,9 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
   memcpy(rec + lay.off_cards, cards.data(), cards.size() * sizeof(ygo_card));
   const int n_opt = std::min(in->n_options, cfg->max_options);
   const size_t opt_bytes = (size_t)ygk::option_bytes(cfg->max_multi_select);
+  const size_t off_opts = (size_t)lay.off_cards + cards.size() * sizeof(ygo_card);  // right behind the listed cards
   for (int i = 0; i < n_opt; ++i) {
-    ygo_option_head* oh = (ygo_option_head*)(rec + lay.off_opts + (size_t)i * opt_bytes);
+    ygo_option_head* oh = (ygo_option_head*)(rec + off_opts + (size_t)i * opt_bytes);
     uint32_t* keys = (uint32_t*)(oh + 1);  // spec references (ygo_kernels.hpp spec_ref)
     SpecList specs;
     if (!in->options[i]) return fail(EP_ERR_INVALID, "null option string");

@@ -63,7 +63,7 @@ __host__ __device__ inline int option_bytes(int mms) { return (int)sizeof(ygo_op
 struct Carve {
   int cards, actions, hact, global, hcids, spec, stage, wave_stride, total, spec_stride;
   int zero_bytes;                               // [cards, spec end) starts every env as zeros
-  int off_hist, off_cards, off_opts, rec_bytes; // record layout (include/envpool_amd_ygo.h)
+  int off_hist, off_cards, rec_bytes;           // record layout (include/envpool_amd_ygo.h); options at off_cards + 16 * n_cards
   int stage_bytes;                              // landing area of the record in LDS (whole 1 KiB LDS-DMA instructions per span)
 };
 // direct-mapped spec table of one env: [2 players][7 locations][max_cards sequences] plus
@@ -80,14 +80,11 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
   Carve c;
   c.off_hist = 64;
   // the card array comes LAST: only its used prefix is fetched
-  c.off_opts = c.off_hist + al16(n_hist * nf);
-  c.off_cards = al16(c.off_opts + max_options * option_bytes(mms));
-  c.rec_bytes = al16(c.off_cards + R * (int)sizeof(ygo_card));
+  c.off_cards = c.off_hist + al16(n_hist * nf);
+  c.rec_bytes = al16(c.off_cards + R * (int)sizeof(ygo_card) + max_options * option_bytes(mms));
   // every LDS-DMA instruction writes a whole KiB (lanes past the end of a span repeat its last
   // piece): the landing area reaches to where the last instruction of either span can write
-  c.stage_bytes = max(max(c.off_hist + ((c.off_cards - c.off_hist + 1023) & ~1023),
-                          c.off_cards + ((R * (int)sizeof(ygo_card) + 1023) & ~1023)),
-                      (c.rec_bytes + 1023) & ~1023);
+  c.stage_bytes = max((c.rec_bytes + 1023) & ~1023, c.off_hist + ((c.rec_bytes - c.off_hist + 1023) & ~1023));
   int o = 0;
   c.cards = o;   o += max(al16(R * 39) + 16, c.stage_bytes);  // doubles as the record's landing area
   c.actions = o; o += al16(max_options * nf) + 16;
@@ -451,12 +448,12 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
       }
     }
     const int n_listed = min(n_cards, R);
-    if (!a.lean_fetch) {
-      fetch_span(0, min((cv.off_cards >> 4) + n_listed, cv.rec_bytes >> 4), 1);
-    } else if (!no_options) {
-      const int used_opts_end = (cv.off_opts + n_opt * option_bytes(a.mms) + 15) >> 4;
-      fetch_span(cv.off_hist >> 4, used_opts_end - (cv.off_hist >> 4), 0);
-      fetch_span(cv.off_cards >> 4, n_listed, 0);
+    // the used part of a record is contiguous: header | history ring | listed cards | used options
+    const int off_opts = cv.off_cards + n_listed * (int)sizeof(ygo_card);
+    if (!no_options) {
+      const int used_end = min((off_opts + n_opt * option_bytes(a.mms) + 15) >> 4, cv.rec_bytes >> 4);
+      if (!a.lean_fetch) fetch_span(0, used_end, 1);
+      else fetch_span(cv.off_hist >> 4, used_end - (cv.off_hist >> 4), 0);
     }
 
     // obs:global_ (:1605-1620), eight bytes built as two wave-uniform words: lp of to_play and of
@@ -495,7 +492,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
         cw[it][0] = c4.x; cw[it][1] = c4.y; cw[it][2] = c4.z; cw[it][3] = c4.w;
       }
       {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + cv.off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + off_opts) + min(lane, a.max_options - 1) * (3 + a.mms);
 #pragma unroll
         for (int d = 0; d < 3 + EP_YGO_MAX_SPECS; ++d) mw[d] = src[d];  // (past 3 + mms: in-bounds bytes nobody uses)
       }

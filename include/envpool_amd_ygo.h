@@ -46,11 +46,12 @@ typedef struct {
  * record := ygo_header (64 B)
  *           | history ring of the to_play player, n_history_actions*n_action_feats bytes,
  *             raw ring order (ygopro.h:1304-1314), padded to 16 B
- *           | max_options x { ygo_option_head, uint32_t spec_ref[max_multi_select] }, padded to 16 B
- *           | ygo_card[2*max_cards]        (only the first sum(loc_count of listed
- *                                           locations) entries are meaningful: the device
- *                                           fetches that prefix only)
- * padded to a multiple of 256 B: ep_ygo_record_stride() (3328 B at the default config). */
+ *           | ygo_card[n_cards], n_cards = sum(loc_count of the listed locations) <= 2*max_cards
+ *           | min(num_options, max_options) x { ygo_option_head, uint32_t spec_ref[max_multi_select] }
+ * so the used part of a record is one contiguous prefix (about 1.5 KB in a mid-game state): the
+ * device fetches that prefix only - from HBM or, in the zero-copy mode, over PCIe. Records sit at
+ * a fixed stride, the maximum size padded to a multiple of 256 B: ep_ygo_record_stride()
+ * (3328 B at the default config). */
 typedef struct {
   uint8_t to_play;      /* to_play_ (:1281) */
   uint8_t turn_player;  /* tp_ (:1275) */

@@ -99,8 +99,8 @@ def test_emitter_record_fields():
   assert mask == 1  # only "oh1" matters; "g9" is not an opponent-hand spec
   loc = rec[48:62].reshape(2, 7)
   assert loc.tolist() == [[0, 0, 3, 0, 0, 0, 0], [2, 2, 0, 0, 0, 0, 0]]
-  off_opts = 64 + ((16 * 19 + 15) // 16) * 16
-  off_cards = (off_opts + 16 * (12 + 4 * 5) + 15) // 16 * 16
+  off_cards = 64 + ((16 * 19 + 15) // 16) * 16
+  off_opts = off_cards + 5 * 16  # the options follow the record's own (five) cards
   cards = np.frombuffer(rec[off_cards:off_cards + 5 * 16].tobytes(), dtype=np.dtype(
     [("code", "<u4"), ("ctrl", "u1"), ("loc", "u1"), ("seq", "u1"), ("pos", "u1"), ("level", "u1"), ("rank", "u1"),
      ("link", "u1"), ("mat", "u1"), ("atk", "<u2"), ("def", "<u2")]))
@@ -126,7 +126,7 @@ def test_emitter_option_grammar(msg, opt, feat_col, val):
   arr, keep = ygo_build.batch_of([{"msg": msg, "options": [opt]}])
   recs, status = capi_ygo.emit_records(cfg, arr, 1)
   assert status[0] == 0
-  off_opts = 64 + 304
+  off_opts = 64 + 304  # no cards in this state: the options follow the history ring directly
   feats = recs[0][off_opts:off_opts + 9].tolist()
   want = [0] * 9
   want[0] = [11, 16, 15, 20, 19, 12, 13, 10, 26, 14, 18, 23, 24, 141].index(msg) + 1
