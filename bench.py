@@ -308,6 +308,26 @@ def main():
           ygo["roofline"]["traffic"] = t * big["records_per_launch"]
     except Exception as ex:  # the headline line must still be printed
       ygo = {"error": repr(ex)}
+  elif world > 1 and not args.no_ygo:
+    # N > 1: every rank encodes its own shard of envs (no exchange on this path either); the
+    # aggregate is all ranks' records over the slowest rank's time
+    try:
+      from tools import bench_ygo
+      r = bench_ygo.run_shard(dev_index, barrier)
+      tm = torch.tensor([r["large_wall_s"], r["pipeline_wall_s"]], dtype=torch.float64, device="cpu" if rehearse else dev)
+      dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+      if rank == 0:
+        ygo = {
+          "metric": "ygopro obs-encodes/s", "unit": "encodes/s", "scaling": "weak",
+          "value_device_resident": world * r["large_records"] / float(tm[0].item()),
+          "value_config5_host_records_pcie_inclusive": world * r["pipeline_records"] / float(tm[1].item()),
+          "config": {"workload": f"YGOPro-v0 observation-encode tail, default config, synthetic duel states, {world} ranks: "
+                                 f"{r['records_per_launch']} device-resident records per launch per GPU, and BASELINE config 5's "
+                                 f"per-GPU shape, {r['records_per_step']} host records per step written in place into the pinned slots"},
+        }
+    except Exception as ex:
+      if rank == 0:
+        ygo = {"error": repr(ex)}
 
   if rank == 0:
     traffic = None

@@ -12,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
+def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0, device=0):
   import numpy as np
   import torch
 
@@ -20,7 +20,8 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
   from tools import ygo_synth
 
   L = capi_ygo.lib()
-  cfg = capi_ygo.default_config(max_batch=n_big, ring_depth=2)
+  dev = f"cuda:{device}"
+  cfg = capi_ygo.default_config(max_batch=n_big, ring_depth=2, device_id=device)
   table = ygo_synth.make_table(1000, seed=0)
   n_gen = 8192
   sb = ygo_synth.SynthBatch(cfg, table, n_gen, seed=0)
@@ -45,7 +46,7 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
   enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
   h = enc.handle
   reps = n_big // n_gen
-  big = torch.from_numpy(np.tile(recs, (reps, 1))).to("cuda:0")
+  big = torch.from_numpy(np.tile(recs, (reps, 1))).to(dev)
   torch.cuda.synchronize()
   b = capi.Batch()
   ok = (0, capi.EP_ERR_ACTION_CHECK)
@@ -71,7 +72,7 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
   zero_copy = os.environ.get("EP_YGO_ZERO_COPY", "1") != "0"  # the library's default (ygo.hip)
 
   def pipeline(n_rec, steps=400):
-    cfgp = capi_ygo.default_config(max_batch=n_rec, ring_depth=4)
+    cfgp = capi_ygo.default_config(max_batch=n_rec, ring_depth=4, device_id=device)
     encp = capi_ygo.YgoEncoderC(cfgp, table, len(table))
     hp = encp.handle
     recp = np.ascontiguousarray(recs[:n_rec])
@@ -118,7 +119,7 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
     encp.close()
     # the H2D copy alone, same bytes, pinned source: what the pipeline cannot go below
     src = torch.from_numpy(recp).pin_memory()
-    dst = torch.empty_like(src, device="cuda:0")
+    dst = torch.empty_like(src, device=dev)
     for _ in range(4):
       dst.copy_(src, non_blocking=True)
     torch.cuda.synchronize()
@@ -155,6 +156,70 @@ def run(n_big=65536, n_cfg3=1024, iters=20, cpu_seconds=0.0):
     res["cpu_oracle_encodes_per_s_1core"] = done / (time.perf_counter() - c0)
   return res
 
+
+
+def run_shard(device, barrier, n_big=65536, n_step=512, iters=20, steps=200):
+  """One rank's share of a multi-GPU run (envs shard by env_id, no exchange): the device-resident
+  large batch and the per-GPU shape of BASELINE config 5 (512 host records per step through the
+  pinned pipeline), each timed between barriers. Returns the two wall times; the caller takes the
+  maximum over ranks."""
+  import numpy as np
+  import torch
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  L = capi_ygo.lib()
+  dev = f"cuda:{device}"
+  cfg = capi_ygo.default_config(max_batch=n_big, ring_depth=2, device_id=device)
+  table = ygo_synth.make_table(1000, seed=0)
+  n_gen = 8192
+  sb = ygo_synth.SynthBatch(cfg, table, n_gen, seed=0)
+  recs, _ = capi_ygo.emit_records(cfg, sb.raw, n_gen)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  big = torch.from_numpy(np.tile(recs, (n_big // n_gen, 1))).to(dev)
+  torch.cuda.synchronize()
+  b = capi.Batch()
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  for _ in range(3):
+    assert L.ep_ygo_featurize(enc.handle, big.data_ptr(), n_big, capi.EP_MEM_DEVICE, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    assert L.ep_ygo_featurize(enc.handle, big.data_ptr(), n_big, capi.EP_MEM_DEVICE, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  barrier()
+  t_big = time.perf_counter() - t0
+  enc.close()
+  del big
+
+  cfgp = capi_ygo.default_config(max_batch=n_step, ring_depth=4, device_id=device)
+  encp = capi_ygo.YgoEncoderC(cfgp, table, len(table))
+  hp = encp.handle
+  recp = np.ascontiguousarray(recs[:n_step])
+  slot = C.c_void_p()
+  for _ in range(4):
+    assert L.ep_ygo_acquire_slot(hp, C.byref(slot)) == 0
+    C.memmove(slot, recp.ctypes.data, recp.nbytes)
+    assert L.ep_ygo_commit_slot(hp, n_step) == 0
+    assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  barrier()
+  t0 = time.perf_counter()
+  inflight = 0
+  for _ in range(steps):
+    assert L.ep_ygo_acquire_slot(hp, C.byref(slot)) == 0
+    assert L.ep_ygo_commit_slot(hp, n_step) == 0
+    inflight += 1
+    if inflight == 3:
+      assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      inflight -= 1
+  while inflight:
+    assert L.ep_ygo_collect(hp, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    inflight -= 1
+  barrier()
+  t_step = time.perf_counter() - t0
+  encp.close()
+  return {"large_wall_s": t_big, "large_records": n_big * iters, "pipeline_wall_s": t_step, "pipeline_records": n_step * steps,
+          "records_per_launch": n_big, "records_per_step": n_step}
 
 if __name__ == "__main__":
   print(json.dumps(run(cpu_seconds=float(os.environ.get("EP_YGO_CPU_SECONDS", "3")))))
