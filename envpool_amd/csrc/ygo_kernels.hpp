@@ -470,9 +470,10 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
               ((uint32_t)to_play == turn_player ? 1u << 16 : 0u);
     }
 
-    // Everything from here on comes in two instantiations: NIT = 1 when the env lists at most 64
-    // cards (one per lane - nearly every duel state), NIT = 4 otherwise (lane l owns cards l,
-    // l+64, l+128, l+192). The choice is wave-uniform.
+    // Everything from here on comes in three instantiations by the number of listed cards: NIT = 1
+    // (at most 64: one per lane), NIT = 2 (at most 128: a mid-game state lists 60-90, the own
+    // deck included), NIT = 4 otherwise (lane l owns cards l, l+64, l+128, l+192). The choice is
+    // wave-uniform.
     auto tail = [&](auto nit_c) {
       constexpr int NIT = decltype(nit_c)::value;
       // the card / option arrays go to their owning lanes: lane l owns cards l, l+64, l+128, l+192
@@ -759,6 +760,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
       flush_env(e, lane);
     };
     if (n_listed <= 64) tail(std::integral_constant<int, 1>{});
+    else if (n_listed <= 128) tail(std::integral_constant<int, 2>{});
     else tail(std::integral_constant<int, 4>{});
     YGO_STAMP(6);
   }
