@@ -50,7 +50,7 @@ SYMBOLS = [
   "ep_ygo_encoder_create", "ep_ygo_encoder_destroy", "ep_ygo_set_card_table", "ep_ygo_record_stride",
   "ep_ygo_action_feats", "ep_ygo_featurize", "ep_ygo_submit", "ep_ygo_collect", "ep_ygo_acquire_slot",
   "ep_ygo_commit_slot", "ep_ygo_sync", "ep_ygo_stream", "ep_ygo_set_timing", "ep_ygo_kernel_time_us",
-  "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy",
+  "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy", "ep_ygo_submit_device",
 ]
 
 _bound = None
@@ -70,6 +70,7 @@ def lib():
     L.ep_ygo_action_feats.argtypes = [C.POINTER(YgoConfig)]
     L.ep_ygo_featurize.argtypes = [vp, vp, i32, i32, i32, C.POINTER(capi.Batch)]
     L.ep_ygo_submit.argtypes = [vp, vp, i32]
+    L.ep_ygo_submit_device.argtypes = [vp, vp, i32]
     L.ep_ygo_collect.argtypes = [vp, i32, C.POINTER(capi.Batch)]
     L.ep_ygo_acquire_slot.argtypes = [vp, C.POINTER(vp)]
     L.ep_ygo_commit_slot.argtypes = [vp, i32]

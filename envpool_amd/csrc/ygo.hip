@@ -470,24 +470,31 @@ int ep_ygo_featurize(ep_ygo_encoder* e, const void* records, int32_t n, int32_t 
     if (rc) return rc;
     return ep_ygo_collect(e, mem_out, out);
   }
-  // device-resident records: no staging, the kernel reads the caller's buffer
-  {
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
-    if (e->submit_idx - e->collect_idx >= e->slots.size()) return fail(EP_ERR_RING_FULL, "ring full");
-    HIP_TRY(hipSetDevice(e->device));
-    const int si = (int)(e->submit_idx % e->slots.size());
-    Slot& s = e->slots[si];
-    s.n = n;
-    if (n > 0) {
-      int rc = launch(e, (const char*)records, n, si);
-      if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(s.done, e->stream));
-    s.busy = true;
-    e->submit_idx++;
-  }
+  int rc = ep_ygo_submit_device(e, records, n);
+  if (rc) return rc;
   return ep_ygo_collect(e, mem_out, out);
+}
+
+int ep_ygo_submit_device(ep_ygo_encoder* e, const void* device_records, int32_t n) {
+  if (!e || (!device_records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
+  // device-resident records: no staging, the kernel reads the caller's buffer
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
+  if (e->submit_idx - e->collect_idx >= e->slots.size())
+    return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
+  HIP_TRY(hipSetDevice(e->device));
+  const int si = (int)(e->submit_idx % e->slots.size());
+  Slot& s = e->slots[si];
+  s.n = n;
+  if (n > 0) {
+    int rc = launch(e, (const char*)device_records, n, si);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(s.done, e->stream));
+  s.busy = true;
+  e->submit_idx++;
+  return EP_OK;
 }
 
 int ep_ygo_sync(ep_ygo_encoder* e) {

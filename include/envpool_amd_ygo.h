@@ -156,6 +156,11 @@ int ep_ygo_featurize(ep_ygo_encoder* enc, const void* records, int32_t n, int32_
  * overlap of host duel results on a side stream"). */
 int ep_ygo_submit(ep_ygo_encoder* enc, const void* host_records, int32_t n);
 int ep_ygo_collect(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);
+/* ep_ygo_submit for records that already sit in device memory (n x ep_ygo_record_stride bytes):
+ * the kernel reads the caller's buffer, which must stay untouched until the batch is collected.
+ * Non-blocking like ep_ygo_submit; results come back through ep_ygo_collect in FIFO order with the
+ * host-record batches. (ep_ygo_featurize with EP_MEM_DEVICE input is this + ep_ygo_collect.) */
+int ep_ygo_submit_device(ep_ygo_encoder* enc, const void* device_records, int32_t n);
 /* Direct access to the next pinned staging slot, so host duel threads can emit records in
  * place (no memcpy): acquire -> fill n records -> commit. */
 int ep_ygo_acquire_slot(ep_ygo_encoder* enc, void** pinned_records);

@@ -210,6 +210,14 @@ def test_submit_collect_pipeline_and_device_records(zero_copy):
   got = capi.batch_to_numpy(bt)
   L.ep_batch_release(C.byref(bt))
   _compare(got, want, ok, "device records")
+  # the non-blocking form, two device batches in flight, interleaved with a host batch
+  L = capi_ygo.lib()
+  capi._check(L.ep_ygo_submit_device(enc.handle, t.data_ptr(), recs.shape[0]))
+  enc.submit(batches[1][0])
+  capi._check(L.ep_ygo_submit_device(enc.handle, t.data_ptr(), recs.shape[0]))
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, ok, "submit_device 1")
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), batches[1][1], batches[1][2], "host batch between")
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, ok, "submit_device 2")
 
 
 def test_python_front_end_and_action_mask():
