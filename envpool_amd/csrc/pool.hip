@@ -12,6 +12,7 @@
 //   background zero-fill thread (:82-95)              -> gone; kernels write whole rows.
 //   semaphores / StateBuffer::Wait (state_buffer.h:135-157) -> one hipEvent per slot.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -195,15 +196,21 @@ int drain_timed(ep_pool* p) {
 // have been received; reference: StateBuffer::Allocate throws once alloc_count_ >= batch_)
 bool slot_free_for(ep_pool* p, uint64_t bi) { return bi < p->done_ptr + (uint64_t)p->Q; }
 
-// Records a completion event for launch `lid` on the step stream.
-int mark_launch(ep_pool* p, uint64_t lid) {
+hipEvent_t take_done_event(ep_pool* p) {
   hipEvent_t e = nullptr;
   if (!p->done_ev_pool.empty()) {
     e = p->done_ev_pool.back();
     p->done_ev_pool.pop_back();
-  } else {
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    return nullptr;
   }
+  return e;
+}
+
+// Records a completion event for launch `lid` on the step stream.
+int mark_launch(ep_pool* p, uint64_t lid) {
+  hipEvent_t e = take_done_event(p);
+  if (!e) return fail(EP_ERR_HIP, "hipEventCreate failed");
   HIP_TRY(hipEventRecord(e, p->stream));
   p->inflight.emplace_back(lid, e);
   return EP_OK;
@@ -229,8 +236,10 @@ int wait_launch(ep_pool* p, uint64_t lid) {
 
 // Launch the single-player kernel for items [i0, i0+n) of one send/reset that land in `slot`
 // at rows row0...
+// `done_ev`, when given, rides on the kernel's own dispatch packet as its completion event (no
+// separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-              int slot, int row0, bool force_reset) {
+              int slot, int row0, bool force_reset, hipEvent_t done_ev = nullptr) {
   epk::StepArgs a;
   a.env_id = d_env_id;
   a.players_env_id = d_penv;
@@ -247,9 +256,9 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   {
     TimedScope ts(p);
     if (p->S == 10)
-      hipLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, p->stream, a);
+      hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, p->stream, nullptr, done_ev, 0, a);
     else
-      hipLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, p->stream, a);
+      hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, p->stream, nullptr, done_ev, 0, a);
   }
   HIP_TRY(hipGetLastError());
   return EP_OK;
@@ -283,16 +292,18 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
     // otherwise rows follow the allocation order.
     int row0 = p->is_sync ? i0 : (int)(pos % B);
+    hipEvent_t done_ev = take_done_event(p);
+    if (!done_ev) return fail(EP_ERR_HIP, "hipEventCreate failed");
     int rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
-                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset);
-    if (rc != EP_OK) return rc;
+                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev);
+    if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); return rc; }
     SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
     sh.has_work = true;
     sh.launch_id = ++p->launch_seq;
-    if (int rc2 = mark_launch(p, sh.launch_id)) return rc2;
+    p->inflight.emplace_back(sh.launch_id, done_ev);
     p->alloc_count += cnt;
     i0 += cnt;
   }
