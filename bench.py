@@ -238,7 +238,8 @@ def main():
     s1 = time.perf_counter()
     per_step["host_buffers_pcie_inclusive"] = {
       "value": N * hk / (s1 - s0), "unit": "env-steps/s", "ms_per_step": (s1 - s0) / hk * 1e3,
-      "note": "numpy actions in (4 MiB/step), numpy StateBuffer out (4.4 MiB/step), pageable host memory"}
+      "note": "numpy actions in (4 MiB/step), numpy StateBuffer out (4.4 MiB/step), pageable host memory; "
+              "kernels read the pinned staging area and write the pinned result block over PCIe themselves"}
 
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline:

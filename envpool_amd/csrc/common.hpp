@@ -58,9 +58,15 @@ inline int take_block(const std::shared_ptr<HostBlocks>& hb, void** out) {
       hb->free_list.pop_back();
     }
   }
-  if (!blk) HIP_TRY(hipHostMalloc(&blk, hb->bytes, hipHostMallocDefault));
+  if (!blk) HIP_TRY(hipHostMalloc(&blk, hb->bytes, hipHostMallocMapped));
   *out = blk;
   return EP_OK;
+}
+
+inline void give_block(const std::shared_ptr<HostBlocks>& hb, void* blk) {
+  std::lock_guard<std::mutex> lk(hb->mu);
+  if (hb->alive && hb->free_list.size() < 8) hb->free_list.push_back(blk);
+  else (void)hipHostFree(blk);
 }
 
 inline void retire_blocks(const std::shared_ptr<HostBlocks>& hb) {

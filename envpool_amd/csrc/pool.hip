@@ -44,6 +44,7 @@ struct SlotHost {
   std::vector<std::pair<int64_t, int64_t>> written;  // shared rows written, [a,b)
   bool has_work = false;
   uint64_t launch_id = 0;  // id of the last launch that wrote this slot
+  void* host_blk = nullptr;  // direct host mode: the kernels wrote this batch straight into a pinned block, not the ring
 };
 
 }  // namespace
@@ -52,6 +53,7 @@ struct ep_pool {
   ep_dummy_config cfg{};
   int N = 0, B = 0, P = 0, S = 0, Q = 0;
   bool is_sync = false;
+  bool direct_host = true;  // EP_DIRECT_HOST=0: always stage host batches through the copy engine
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   // device state
@@ -122,8 +124,7 @@ int set_device(ep_pool* p) {
   return EP_OK;
 }
 
-epk::SlotPtrs host_slot_ptrs(ep_pool* p, int slot) {
-  char* b = p->d_ring + (size_t)slot * p->slot_stride;
+epk::SlotPtrs slot_ptrs_at(ep_pool* p, char* b) {  // the key arrays of one batch laid out at `b`
   epk::SlotPtrs s;
   s.env_id = (int32_t*)(b + p->key_off[0]);
   s.penv = (int32_t*)(b + p->key_off[1]);
@@ -138,6 +139,7 @@ epk::SlotPtrs host_slot_ptrs(ep_pool* p, int slot) {
   s.pid = (int32_t*)(b + p->key_off[10]);
   return s;
 }
+epk::SlotPtrs host_slot_ptrs(ep_pool* p, int slot) { return slot_ptrs_at(p, p->d_ring + (size_t)slot * p->slot_stride); }
 
 epk::PoolConst pool_const(ep_pool* p) {
   epk::PoolConst pc;
@@ -239,14 +241,16 @@ int wait_launch(ep_pool* p, uint64_t lid) {
 // `done_ev`, when given, rides on the kernel's own dispatch packet as its completion event (no
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-              int slot, int row0, bool force_reset, hipEvent_t done_ev = nullptr) {
+              int slot, int row0, bool force_reset, hipEvent_t done_ev = nullptr, char* out_base = nullptr,
+              hipStream_t st = nullptr) {
+  if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
   a.players_env_id = d_penv;
   a.list_action = d_la;
   a.env = p->d_env;
   a.stats = p->stats;
-  a.slot = host_slot_ptrs(p, slot);
+  a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
   a.err = p->d_err + slot;
   a.pc = pool_const(p);
   a.n = n;
@@ -256,9 +260,9 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   {
     TimedScope ts(p);
     if (p->S == 10)
-      hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, p->stream, nullptr, done_ev, 0, a);
+      hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, st, nullptr, done_ev, 0, a);
     else
-      hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, p->stream, nullptr, done_ev, 0, a);
+      hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, st, nullptr, done_ev, 0, a);
   }
   HIP_TRY(hipGetLastError());
   return EP_OK;
@@ -266,8 +270,11 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
 
 // Common tail of send/reset once the action arrays are on the device.
 // `n` items; multi-player: `np_rows` rows in players.env_id.
+// `row_base` / `out_base`: direct host mode sends one batch as several calls (row_base = rows
+// already sent) whose kernels write into a pinned host block instead of the ring slot.
 int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
-                   int n, int np_rows, bool force_reset) {
+                   int n, int np_rows, bool force_reset, int row_base = 0, char* out_base = nullptr,
+                   hipStream_t st = nullptr) {
   if (n == 0) return EP_OK;
   const uint64_t B = (uint64_t)p->B;
   // ring capacity check for every batch this call touches
@@ -291,11 +298,11 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     int cnt = std::min(room, n - i0);
     // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
     // otherwise rows follow the allocation order.
-    int row0 = p->is_sync ? i0 : (int)(pos % B);
+    int row0 = p->is_sync ? row_base + i0 : (int)(pos % B);
     hipEvent_t done_ev = take_done_event(p);
     if (!done_ev) return fail(EP_ERR_HIP, "hipEventCreate failed");
     int rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
-                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev);
+                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev, out_base, st);
     if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); return rc; }
     SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
@@ -390,6 +397,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (p->Q < 2) return fail(EP_ERR_INVALID, "ring_depth must be >= 2");
   p->device = cfg->device_id;
   if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
+  if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -450,7 +458,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->A = 4;
   p->stage_bytes = align_up(4 * (size_t)p->N) + align_up(4 * (size_t)p->N * p->P) +
                    align_up(48 * (size_t)p->N) + 2 * align_up(4 * (size_t)p->N * p->P);
-  HIP_TRY(hipHostMalloc((void**)&p->h_stage, p->stage_bytes * (size_t)p->A, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&p->h_stage, p->stage_bytes * (size_t)p->A, hipHostMallocMapped));
   HIP_TRY(hipMalloc((void**)&p->d_stage, p->stage_bytes * (size_t)p->A));
   p->stage_free.resize(p->A);
   p->stage_copied.resize(p->A);
@@ -500,6 +508,8 @@ int ep_pool_destroy(ep_pool* p) {
   if (p->h_err) (void)hipHostFree(p->h_err);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   (void)hipFree(p->d_stage);
+  for (auto& sh : p->slots)
+    if (sh.host_blk) (void)hipHostFree(sh.host_blk);  // a direct-mode batch nobody received
   epc::retire_blocks(p->blocks);
   (void)hipStreamDestroy(p->stream);
   (void)hipStreamDestroy(p->copy_stream);
@@ -555,12 +565,60 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   char* d = p->d_stage + (size_t)a * p->stage_bytes;
   size_t o0 = 0, o1 = align_up(4 * (size_t)n), o2 = o1 + align_up(4 * (size_t)np_rows);
   size_t total = o2 + 48 * (size_t)n;
-  memcpy(h + o0, arrays[0], 4 * (size_t)n);
-  memcpy(h + o1, arrays[1], 4 * (size_t)np_rows);
-  memcpy(h + o2, arrays[2], 48 * (size_t)n);
+  // Direct host mode: a whole sync batch from host buffers, to be received as host buffers (the
+  // numpy step() of the reference's API). No copy engine: the batch goes in pieces, each copied
+  // into the pinned staging area and stepped by a kernel that READS the staging area and WRITES
+  // the result block over PCIe itself - the two directions and the host's memcpy of the next
+  // piece overlap. (A later recv that asks for device views copies the block into the ring.)
+  {
+    const uint64_t pos = p->alloc_count;
+    SlotHost& sh0 = p->slots[(int)((pos / (uint64_t)p->B) % (uint64_t)p->Q)];
+    if (p->direct_host && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= 4096 &&
+        sh0.alloc_count == 0 && !sh0.has_work && !sh0.host_blk && slot_free_for(p, pos / (uint64_t)p->B)) {
+      void* blk = nullptr;
+      if ((rc = epc::take_block(p->blocks, &blk))) return rc;
+      void *blk_dev = nullptr, *stage_dev = nullptr;
+      if (hipHostGetDevicePointer(&blk_dev, blk, 0) == hipSuccess && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
+        const char* sd = (const char*)stage_dev;
+        const int pieces = n >= 32768 ? 4 : 2;
+        const int step = (((int)n + pieces - 1) / pieces + 255) & ~255;
+        for (int c0 = 0; c0 < (int)n && rc == EP_OK; c0 += step) {
+          const int cnt = std::min(step, (int)n - c0);
+          memcpy(h + o0 + 4 * (size_t)c0, (const int32_t*)arrays[0] + c0, 4 * (size_t)cnt);
+          memcpy(h + o1 + 4 * (size_t)c0, (const int32_t*)arrays[1] + c0, 4 * (size_t)cnt);
+          memcpy(h + o2 + 48 * (size_t)c0, (const char*)arrays[2] + 48 * (size_t)c0, 48 * (size_t)cnt);
+          rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0,
+                              (const double*)(sd + o2) + 6 * (size_t)c0, cnt, cnt, false, c0, (char*)blk_dev);
+        }
+        if (rc == EP_OK) sh0.host_blk = blk;
+        else epc::give_block(p->blocks, blk);
+        int rc2 = stage_release(p, a);
+        return rc ? rc : rc2;
+      }
+      epc::give_block(p->blocks, blk);  // not mappable: the staged way below
+    }
+  }
   // players.action / players.id (arrays[3], arrays[4]) are never read by DummyEnv::Step
   // (dummy_envpool.h:173-210), so they are not shipped to the device.
-  if ((rc = stage_commit(p, a, total))) return rc;
+  memcpy(h + o0, arrays[0], 4 * (size_t)n);
+  memcpy(h + o1, arrays[1], 4 * (size_t)np_rows);
+  constexpr size_t kChunk = 768 << 10;
+  if (total <= kChunk) {
+    memcpy(h + o2, arrays[2], 48 * (size_t)n);
+    if ((rc = stage_commit(p, a, total))) return rc;
+  } else {
+    // large batches: the pageable -> pinned memcpy of one piece runs while the copy engine ships
+    // the piece before it (the H2D copy used to start only after the whole memcpy)
+    HIP_TRY(hipMemcpyAsync(d, h, o2, hipMemcpyHostToDevice, p->copy_stream));
+    const size_t la_bytes = 48 * (size_t)n;
+    for (size_t off = 0; off < la_bytes; off += kChunk) {
+      const size_t len = std::min(kChunk, la_bytes - off);
+      memcpy(h + o2 + off, (const char*)arrays[2] + off, len);
+      HIP_TRY(hipMemcpyAsync(d + o2 + off, h + o2 + off, len, hipMemcpyHostToDevice, p->copy_stream));
+    }
+    HIP_TRY(hipEventRecord(p->stage_copied[a], p->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->stage_copied[a], 0));
+  }
   rc = enqueue_slices(p, (const int32_t*)(d + o0), (const int32_t*)(d + o1), (const double*)(d + o2), (int)n,
                       (int)np_rows, false);
   int rc2 = stage_release(p, a);
@@ -668,7 +726,18 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
   if (consumer && p->P > 1)
     return fail(EP_ERR_INVALID, "ep_pool_recv_on_stream needs max_num_players == 1 (the player row count of a "
                                 "multi-player batch is only known on the device)");
-  if (sh.has_work && !consumer)
+  // host output of a single-player pool: the D2H copy below is ordered behind the kernels on the
+  // step stream and one synchronisation at its end serves both (no host round trip in between)
+  if (sh.host_blk && (mem != EP_MEM_HOST || consumer)) {
+    // the batch was written straight into a pinned block (direct host mode) but is wanted as
+    // device views after all: bring it into its ring slot
+    HIP_TRY(hipMemcpyAsync(p->d_ring + (size_t)slot * p->slot_stride, sh.host_blk, p->slot_stride, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    epc::give_block(p->blocks, sh.host_blk);
+    sh.host_blk = nullptr;
+  }
+  const bool one_sync = mem == EP_MEM_HOST && p->P == 1 && !consumer;
+  if (sh.has_work && !consumer && !one_sync)
     if ((rc = wait_launch(p, sh.launch_id))) return rc;
   if (p->P > 1) {
     HIP_TRY(hipMemcpyAsync(p->h_slot_players + slot, p->d_slot_players + slot, 4, hipMemcpyDeviceToHost, p->stream));
@@ -697,7 +766,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
     }
     if (cur < (int64_t)nrows)
       if ((rc = zero_rows(cur, nrows))) return rc;
-    if (any && !consumer) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (any && !consumer && !one_sync) HIP_TRY(hipStreamSynchronize(p->stream));
   }
   int status = EP_OK;
   if (consumer) {
@@ -717,18 +786,20 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
       p->done_ev_pool.push_back(p->inflight.front().second);
       p->inflight.pop_front();
     }
-  } else if (p->h_err[slot].action_check) {
-    status = fail(EP_ERR_ACTION_CHECK,
-                  "Dummy action self-check failed: list_action lanes differ (the reference aborts "
-                  "here, dummy_envpool.h:189-192)");
-  } else if (p->h_err[slot].env_id_range) {
-    status = fail(EP_ERR_ACTION_CHECK, "an env_id in the sent batch is outside this pool's shard");
   }
-  if (!consumer) {
+  auto read_status = [&]() {  // the slot's error word, once its kernels have run
+    if (p->h_err[slot].action_check) {
+      status = fail(EP_ERR_ACTION_CHECK,
+                    "Dummy action self-check failed: list_action lanes differ (the reference aborts "
+                    "here, dummy_envpool.h:189-192)");
+    } else if (p->h_err[slot].env_id_range) {
+      status = fail(EP_ERR_ACTION_CHECK, "an env_id in the sent batch is outside this pool's shard");
+    }
     p->h_err[slot].action_check = 0;
     p->h_err[slot].env_id_range = 0;
     p->deferred_err[slot] = 0;
-  }
+  };
+  if (!consumer && !one_sync) read_status();
 
   memset(out, 0, sizeof(*out));
   out->num_keys = 12;
@@ -738,10 +809,13 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
   out->seq = p->recv_seq++;
   char* base = nullptr;
   if (mem == EP_MEM_HOST) {
-    void* blk = nullptr;
-    if ((rc = epc::take_block(p->blocks, &blk))) return rc;
+    void* blk = sh.host_blk;  // direct host mode: the kernels are writing (or wrote) it already
+    sh.host_blk = nullptr;
+    const bool filled = blk != nullptr;
+    if (!filled && (rc = epc::take_block(p->blocks, &blk))) return rc;
     char* src = p->d_ring + (size_t)slot * p->slot_stride;
-    if ((size_t)nrows * 2 >= (size_t)p->B) {
+    if (filled) {
+    } else if ((size_t)nrows * 2 >= (size_t)p->B) {
       HIP_TRY(hipMemcpyAsync(blk, src, p->slot_stride, hipMemcpyDeviceToHost, p->stream));
     } else {
       for (int k = 0; k < 11; ++k) {
@@ -750,6 +824,15 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
       }
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (one_sync) {
+      read_status();
+      // everything launched so far has finished: retire the completion events
+      while (!p->inflight.empty()) {
+        p->done_ev_pool.push_back(p->inflight.front().second);
+        p->inflight.pop_front();
+      }
+      p->completed_launch = p->launch_seq;
+    }
     out->owner = new HostBlockOwner{p->blocks, blk};
     base = (char*)blk;
   } else {

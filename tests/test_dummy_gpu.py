@@ -340,3 +340,71 @@ def test_recv_on_stream_policy_loop():
   g2, _ = _pair(num_envs=8, seed=1, max_num_players=2)
   g2._reset(np.arange(8, dtype=np.int32))
   assert L.ep_pool_recv_on_stream(g2.handle, None, C.byref(b)) == capi.EP_ERR_INVALID
+
+
+def test_direct_host_mode_and_mixed_recv_modes():
+  """A whole sync batch sent from host buffers is stepped by kernels that read the pinned staging
+  area and write a pinned result block over PCIe themselves (no copy engine). Received as host
+  arrays, as blocking device views and as stream-ordered device views in turn - the last two find
+  the batch in the host block and bring it into the ring - plus a device-resident send in between
+  and an action-check failure: every step against the oracle."""
+  import ctypes as C
+
+  import torch
+
+  from envpool_amd import capi, interop
+
+  n = 8192
+  g, o = _pair(num_envs=n, seed=11, ring_depth=3)
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  assert_batches_equal(g._recv(), o._recv(), "reset")
+  b = capi.Batch()
+  rng = np.random.default_rng(5)
+
+  def device_batch():
+    out = []
+    for k in range(b.num_keys):
+      a = b.arrays[k]
+      if a.dtype == capi.EP_CONTAINER_I32:
+        out.append(None)
+        continue
+      shape = tuple(a.shape[i] for i in range(a.ndim))
+      out.append(interop.as_torch((a.data, shape, np.dtype(capi._NP[a.dtype]).str), device=dev).cpu().numpy())
+    return out
+
+  for t in range(12):
+    penv = ids + (rng.random(n) < 0.1).astype(np.int32)
+    la = np.repeat(rng.integers(0, 5, size=(n, 1)).astype(np.float64), 6, axis=1)
+    bad = t == 7
+    if bad:
+      la[123, 2] += 1.0  # lanes differ: the reference aborts, here the batch is flagged
+    acts = [ids, penv, la, np.zeros(n, np.int32), np.zeros(n, np.int32)]
+    if t % 4 == 3:  # device-resident send between the host ones
+      tens = [torch.from_numpy(x).to(dev) for x in acts]
+      torch.cuda.synchronize()
+      capi._check(L.ep_pool_send(g.handle, 5, (C.c_void_p * 5)(*[x.data_ptr() for x in tens]), (C.c_int64 * 5)(*[n] * 5), capi.EP_MEM_DEVICE))
+    else:
+      g._send(acts)
+    want = None
+    if not bad:
+      o._send(acts)
+      want = o._recv()
+    mode = t % 3
+    if mode == 0:
+      got = g._recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+      assert (g.last_status == capi.EP_ERR_ACTION_CHECK) == bad
+    elif mode == 1:
+      rc = L.ep_pool_recv(g.handle, capi.EP_MEM_DEVICE, C.byref(b))
+      assert rc == (capi.EP_ERR_ACTION_CHECK if bad else 0)
+      got = device_batch()
+    else:
+      capi._check(L.ep_pool_recv_on_stream(g.handle, None, C.byref(b)))
+      rc = L.ep_pool_sync(g.handle)
+      assert rc == (capi.EP_ERR_ACTION_CHECK if bad else 0)
+      got = device_batch()
+    if bad:
+      break  # the oracle (like the reference) cannot go past a failed self-check
+    assert_batches_equal(got, want, f"t={t} recv mode {mode}")
