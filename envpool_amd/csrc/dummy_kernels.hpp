@@ -257,7 +257,8 @@ __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_b
 struct StepArgs {
   const int32_t* env_id;          // [n] global ids (action key 0)
   const int32_t* players_env_id;  // [n] (action key 1; single player => row i belongs to item i)
-  const double* list_action;      // [n,6] (action key 2)
+  const double* list_action;      // [n,6] (action key 2); null: the lanes were compared on the host, see la_ok
+  const uint32_t* la_ok;          // bit i: the six list_action lanes of item i are equal (direct host mode)
   EnvRec* env;
   StatPtrs stats;
   SlotPtrs slot;
@@ -285,9 +286,14 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
         // ParseAction single-player branch (env.h:115-123) + dummy_envpool.h:179-184
         action_num = (a.players_env_id[i] == eid) ? 1 : 0;
         // dummy_envpool.h:187-192: the six lanes must be equal
-        const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
-        double2 v0 = la[0], v1 = la[1], v2 = la[2];
-        bool ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        bool ok;
+        if (a.list_action) {
+          const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
+          double2 v0 = la[0], v1 = la[1], v2 = la[2];
+          ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        } else {
+          ok = ((a.la_ok[i >> 5] >> (i & 31)) & 1u) != 0;
+        }
         // the reference only reaches the check on the Step branch, not on an auto-reset
         if (!ok && !(rec.state >= episode_len(a.pc.seed, eid))) a.err->action_check = 1u;
       }

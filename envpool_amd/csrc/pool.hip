@@ -13,6 +13,9 @@
 //   semaphores / StateBuffer::Wait (state_buffer.h:135-157) -> one hipEvent per slot.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -242,12 +245,13 @@ int wait_launch(ep_pool* p, uint64_t lid) {
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
               int slot, int row0, bool force_reset, hipEvent_t done_ev = nullptr, char* out_base = nullptr,
-              hipStream_t st = nullptr) {
+              hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
   a.players_env_id = d_penv;
   a.list_action = d_la;
+  a.la_ok = la_ok;
   a.env = p->d_env;
   a.stats = p->stats;
   a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
@@ -274,7 +278,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
 // already sent) whose kernels write into a pinned host block instead of the ring slot.
 int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
                    int n, int np_rows, bool force_reset, int row_base = 0, char* out_base = nullptr,
-                   hipStream_t st = nullptr) {
+                   hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
   if (n == 0) return EP_OK;
   const uint64_t B = (uint64_t)p->B;
   // ring capacity check for every batch this call touches
@@ -302,7 +306,7 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     hipEvent_t done_ev = take_done_event(p);
     if (!done_ev) return fail(EP_ERR_HIP, "hipEventCreate failed");
     int rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
-                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev, out_base, st);
+                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
     if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); return rc; }
     SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
@@ -586,9 +590,31 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
           const int cnt = std::min(step, (int)n - c0);
           memcpy(h + o0 + 4 * (size_t)c0, (const int32_t*)arrays[0] + c0, 4 * (size_t)cnt);
           memcpy(h + o1 + 4 * (size_t)c0, (const int32_t*)arrays[1] + c0, 4 * (size_t)cnt);
-          memcpy(h + o2 + 48 * (size_t)c0, (const char*)arrays[2] + 48 * (size_t)c0, 48 * (size_t)cnt);
-          rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0,
-                              (const double*)(sd + o2) + 6 * (size_t)c0, cnt, cnt, false, c0, (char*)blk_dev);
+          // list_action only matters through "are its six lanes equal" (dummy_envpool.h:187-192):
+          // the comparison is done here, while the 48 bytes per env pass through the host's cache
+          // anyway, and one bit per env crosses PCIe instead (whether a failure counts - only on
+          // the Step branch - is still decided by the kernel, which knows the env's state)
+          uint32_t* bits = (uint32_t*)(h + o2) + (c0 >> 5);
+          const double* la = (const double*)arrays[2] + 6 * (size_t)c0;
+          for (int w0 = 0; w0 < cnt; w0 += 32) {
+            uint32_t m = 0;
+            const int lim = std::min(32, cnt - w0);
+            for (int j = 0; j < lim; ++j) {
+              const double* v = la + 6 * (size_t)(w0 + j);
+#if defined(__SSE2__)
+              const __m128d a01 = _mm_loadu_pd(v), a23 = _mm_loadu_pd(v + 2), a45 = _mm_loadu_pd(v + 4);
+              const __m128d first = _mm_unpacklo_pd(a01, a01);  // IEEE ==, as on the device: NaN differs from itself
+              const __m128d eq = _mm_and_pd(_mm_and_pd(_mm_cmpeq_pd(a01, first), _mm_cmpeq_pd(a23, first)), _mm_cmpeq_pd(a45, first));
+              const bool ok = _mm_movemask_pd(eq) == 3;
+#else
+              const bool ok = (v[0] == v[1]) & (v[0] == v[2]) & (v[0] == v[3]) & (v[0] == v[4]) & (v[0] == v[5]);
+#endif
+              m |= (ok ? 1u : 0u) << j;
+            }
+            bits[w0 >> 5] = m;
+          }
+          rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
+                              c0, (char*)blk_dev, nullptr, (const uint32_t*)(sd + o2) + (c0 >> 5));
         }
         if (rc == EP_OK) sh0.host_blk = blk;
         else epc::give_block(p->blocks, blk);
