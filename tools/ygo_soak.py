@@ -22,7 +22,7 @@ def main(total=int(os.environ.get("SOAK_RECORDS", "600000"))):
   done = 0
   t0 = time.time()
   k = 0
-  stats = {"listed_gt64": 0, "flagged": 0}
+  stats = {"flagged": 0}
   while done < total:
     k += 1
     if k % 3 == 1:
