@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""GPU box: randomised parity soak of the Dummy pool against the oracle - random pool shapes (sync
+and async, one to three players per env), random send sizes, host arrays through the C ABI.
+Exits 1 on the first differing byte."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
+  from envpool_amd import capi
+  from envpool_amd.capi import DummyPoolC
+  from oracle.dummy_oracle import DummyOracle
+  from tests.util import assert_batches_equal, dummy_action
+
+  rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
+  t0 = time.time()
+  steps_total = 0
+  for r in range(rounds):
+    n = int(rng.choice([1, 7, 64, 257, 4096, 5000, 20000, 65536]))
+    P = int(rng.choice([1, 1, 1, 2, 3]))
+    sync = bool(rng.random() < 0.5) or n == 1
+    B = n if sync else int(rng.integers(1, n + 1))
+    seed = int(rng.integers(1, 2000))
+    kw = dict(num_envs=n, batch_size=B, seed=seed, max_num_players=P)  # default ring depth: the reference's queue size
+    g = DummyPoolC(**kw)
+    o = DummyOracle(**{k: v for k, v in kw.items() if k != "ring_depth"})
+    ids = np.arange(n, dtype=np.int32)
+    g._reset(ids); o._reset(ids)
+    outstanding = n
+    steps = int(rng.integers(5, 40))
+    for it in range(steps):
+      while outstanding >= B:
+        got, want = g._recv(), o._recv()
+        assert_batches_equal(got, want, f"pool {kw} it {it}")
+        outstanding -= B
+        last_ids = np.asarray(want[0])
+      if P > 1:  # multi-player action rows need the player layout: send the whole last batch back
+        sel = last_ids.astype(np.int32)
+      elif sync:
+        sel = ids if rng.random() < 0.8 else rng.permutation(n).astype(np.int32)
+      else:
+        uniq = np.unique(last_ids)  # (an env id at most once per send: two slices of one env in one send race in the
+        # reference's thread pool as well)
+        sel = rng.choice(uniq, size=int(rng.integers(1, len(uniq) + 1)), replace=False).astype(np.int32)
+      if P > 1:
+        break  # (multi-player sends are covered by the test-suite; here only reset + first batches)
+      penv = sel + (rng.random(len(sel)) < 0.1).astype(np.int32)
+      a = dummy_action(sel, penv)
+      g._send(a); o._send(a)
+      outstanding += len(sel)
+      steps_total += len(sel)
+    del g
+    print(f"ok pool {r}: {kw} steps={steps} env-steps so far {steps_total} t={time.time() - t0:.0f}s", flush=True)
+  print("dummy soak passed:", rounds, "pools,", steps_total, "env-steps")
+
+
+if __name__ == "__main__":
+  main()
