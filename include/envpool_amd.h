@@ -128,7 +128,9 @@ int ep_pool_reset(ep_pool* pool, const int32_t* env_ids, int32_t n, int32_t mem)
  * `leading_dims[k]` its leading dimension. Non-blocking: the step kernel is
  * enqueued on the pool's stream and the call returns. Host arrays are fully
  * consumed (copied to pinned staging) before return; device arrays must stay
- * untouched until the matching recv. */
+ * untouched until the matching recv. An env_id may appear at most once in one
+ * send: all items of a send are stepped concurrently (the reference's worker
+ * threads race on such input as well). */
 int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
                  const int64_t* leading_dims, int32_t mem);
 
