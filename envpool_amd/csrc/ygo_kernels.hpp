@@ -345,15 +345,18 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
   };
 
   // Per env, in this order:
-  //   A  the record travels HBM -> LDS by LDS-DMA (no VGPR round trip) into the region where the
-  //      card image is built later; meanwhile the small images and the spec table are zeroed
-  //      (the reference's fresh zero-filled StateBuffer, array.h:77-81)
-  //   B  header -> scalars, packed card / option / history words -> lanes, hash probes issued
+  //   A  the header arrives by scalar loads; (records in HBM: the first KiB of the record is on
+  //      its way into LDS by LDS-DMA meanwhile, no VGPR round trip, into the region where the card
+  //      image is built later;) the small images and the spec table are zeroed (the reference's
+  //      fresh zero-filled StateBuffer, array.h:77-81)
+  //   B  header -> scalars: segment walk, obs:global_; the rest of the record's used prefix is
+  //      fetched; then, per instantiation (1, 2 or 4 cards per lane): packed card / option words
+  //      -> lanes, history rows rotated into their image, hash probes issued
   //   D  the landing area becomes the zeroed card image
-  //   E  placeholder rows, obs:global_, history rotation, option feature bytes
+  //   E  placeholder rows, option feature bytes
   //   F  probes settled
-  //   C  scalar outputs (after F: VMEM retires in issue order)
-  //   H  rows, options, history (LDS only), then the images leave the CU
+  //   C  scalar outputs and obs:global_ (after F: VMEM retires in issue order)
+  //   H  rows (the card image leaves the CU right behind them), options, then the small images
   {
     bool bad_u = false;   // raised in wave-uniform code
     uint32_t badv = 0;    // raised per lane (a VGPR flag: no exec-mask bookkeeping around it)
