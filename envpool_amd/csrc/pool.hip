@@ -13,8 +13,8 @@
 //   semaphores / StateBuffer::Wait (state_buffer.h:135-157) -> one hipEvent per slot.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#if defined(__SSE2__)
-#include <emmintrin.h>
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
 #endif
 
 #include <algorithm>
@@ -344,6 +344,41 @@ int stage_release(ep_pool* p, int a) {
   return EP_OK;
 }
 
+// bit j of bits[j / 32]: the six list_action lanes of item j are equal (IEEE ==, as the device
+// compares them: NaN differs from itself, -0 equals +0). Host-only code.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target("avx2"))) void la_lanes_equal_avx2(const double* la, int cnt, uint32_t* bits) {
+  for (int w0 = 0; w0 < cnt; w0 += 32) {
+    uint32_t m = 0;
+    const int lim = std::min(32, cnt - w0);
+    for (int j = 0; j < lim; ++j) {
+      const double* v = la + 6 * (size_t)(w0 + j);
+      const __m256d first = _mm256_broadcast_sd(v);
+      const __m256d eq = _mm256_and_pd(_mm256_cmp_pd(_mm256_loadu_pd(v), first, _CMP_EQ_OQ),
+                                       _mm256_cmp_pd(_mm256_loadu_pd(v + 2), first, _CMP_EQ_OQ));
+      m |= (_mm256_movemask_pd(eq) == 0xf ? 1u : 0u) << j;
+    }
+    bits[w0 >> 5] = m;
+  }
+}
+#endif
+void la_lanes_equal(const double* la, int cnt, uint32_t* bits) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return la_lanes_equal_avx2(la, cnt, bits);
+#endif
+  for (int w0 = 0; w0 < cnt; w0 += 32) {
+    uint32_t m = 0;
+    const int lim = std::min(32, cnt - w0);
+    for (int j = 0; j < lim; ++j) {
+      const double* v = la + 6 * (size_t)(w0 + j);
+      const bool ok = (v[0] == v[1]) & (v[0] == v[2]) & (v[0] == v[3]) & (v[0] == v[4]) & (v[0] == v[5]);
+      m |= (ok ? 1u : 0u) << j;
+    }
+    bits[w0 >> 5] = m;
+  }
+}
+
 int validate_ids_host(ep_pool* p, const int32_t* ids, int n) {
   for (int i = 0; i < n; ++i) {
     int64_t local = (int64_t)ids[i] - p->cfg.env_id_offset;
@@ -594,25 +629,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
           // the comparison is done here, while the 48 bytes per env pass through the host's cache
           // anyway, and one bit per env crosses PCIe instead (whether a failure counts - only on
           // the Step branch - is still decided by the kernel, which knows the env's state)
-          uint32_t* bits = (uint32_t*)(h + o2) + (c0 >> 5);
-          const double* la = (const double*)arrays[2] + 6 * (size_t)c0;
-          for (int w0 = 0; w0 < cnt; w0 += 32) {
-            uint32_t m = 0;
-            const int lim = std::min(32, cnt - w0);
-            for (int j = 0; j < lim; ++j) {
-              const double* v = la + 6 * (size_t)(w0 + j);
-#if defined(__SSE2__)
-              const __m128d a01 = _mm_loadu_pd(v), a23 = _mm_loadu_pd(v + 2), a45 = _mm_loadu_pd(v + 4);
-              const __m128d first = _mm_unpacklo_pd(a01, a01);  // IEEE ==, as on the device: NaN differs from itself
-              const __m128d eq = _mm_and_pd(_mm_and_pd(_mm_cmpeq_pd(a01, first), _mm_cmpeq_pd(a23, first)), _mm_cmpeq_pd(a45, first));
-              const bool ok = _mm_movemask_pd(eq) == 3;
-#else
-              const bool ok = (v[0] == v[1]) & (v[0] == v[2]) & (v[0] == v[3]) & (v[0] == v[4]) & (v[0] == v[5]);
-#endif
-              m |= (ok ? 1u : 0u) << j;
-            }
-            bits[w0 >> 5] = m;
-          }
+          la_lanes_equal((const double*)arrays[2] + 6 * (size_t)c0, cnt, (uint32_t*)(h + o2) + (c0 >> 5));
           rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
                               c0, (char*)blk_dev, nullptr, (const uint32_t*)(sd + o2) + (c0 >> 5));
         }
