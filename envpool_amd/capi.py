@@ -10,7 +10,7 @@ import numpy as np
 from ._loader import load_library
 
 EP_OK, EP_ERR_INVALID, EP_ERR_HIP, EP_ERR_NO_DEVICE = 0, 1, 2, 3
-EP_ERR_WOULD_BLOCK, EP_ERR_RING_FULL, EP_ERR_ACTION_CHECK, EP_ERR_TOO_LARGE = 4, 5, 6, 7
+EP_ERR_WOULD_BLOCK, EP_ERR_RING_FULL, EP_ERR_ACTION_CHECK, EP_ERR_TOO_LARGE, EP_ERR_DUP_ENV = 4, 5, 6, 7, 8
 EP_MEM_HOST, EP_MEM_DEVICE = 0, 1
 EP_I32, EP_F32, EP_F64, EP_BOOL, EP_U8, EP_CONTAINER_I32 = range(6)
 EP_MAX_KEYS, EP_MAX_NDIM = 20, 4
@@ -37,7 +37,7 @@ class Batch(C.Structure):
 
 SYMBOLS = [
   "ep_dummy_pool_create", "ep_pool_destroy", "ep_pool_reset", "ep_pool_send", "ep_pool_recv",
-  "ep_pool_recv_many", "ep_pool_recv_on_stream", "ep_pool_episode_stats_async",
+  "ep_pool_recv_many", "ep_pool_recv_on_stream", "ep_pool_set_recv_timeout", "ep_pool_episode_stats_async",
   "ep_batch_release", "ep_pool_rollout", "ep_pool_sync", "ep_pool_episode_stats",
   "ep_pool_checkpoint_bytes", "ep_pool_checkpoint_save", "ep_pool_checkpoint_restore",
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
@@ -60,6 +60,7 @@ def lib():
     L.ep_pool_recv.argtypes = [vp, i32, C.POINTER(Batch)]
     L.ep_pool_recv_many.argtypes = [vp, i32, i32, C.POINTER(Batch)]
     L.ep_pool_recv_on_stream.argtypes = [vp, vp, C.POINTER(Batch)]
+    L.ep_pool_set_recv_timeout.argtypes = [vp, i64]
     L.ep_pool_episode_stats_async.argtypes = [vp, vp, vp, vp, vp]
     L.ep_batch_release.argtypes = [C.POINTER(Batch)]
     L.ep_pool_rollout.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
@@ -126,6 +127,9 @@ class DummyPoolC:
     h = C.c_void_p()
     _check(self._L.ep_dummy_pool_create(C.byref(cfg), C.byref(h)))
     self._h = h
+
+  def set_recv_timeout(self, ms):
+    _check(self._L.ep_pool_set_recv_timeout(self._h, ms))
 
   def close(self):
     if getattr(self, "_h", None):

@@ -82,7 +82,17 @@ struct StatPtrs {
 struct ErrWords {
   uint32_t action_check;  // list_action lanes differ (dummy_envpool.h:189-192 CHECK_EQ)
   uint32_t env_id_range;  // env_id outside this pool's shard
+  uint32_t dup_env;       // one launch named an env twice: its two items raced (device-memory sends only;
+                          // host-memory sends are split on the host so that such items run in order)
+  uint32_t pad;
 };
+
+// "Written exactly once" check of a device-memory send: every env carries the stamp
+// of the last launch that stepped it; an item that finds its own launch's stamp already there is
+// the second item of that env in one launch. One L2 atomic per item, no other ordering needed.
+__device__ __forceinline__ bool stamp_seen(uint32_t* stamp, int32_t local, uint32_t val) {
+  return atomicExch(&stamp[local], val) == val;
+}
 
 struct PoolConst {
   int32_t N;        // local envs
@@ -263,6 +273,8 @@ struct StepArgs {
   StatPtrs stats;
   SlotPtrs slot;
   ErrWords* err;
+  uint32_t* stamp;     // [N] per-env launch stamps, or null (host-validated send: no check needed)
+  uint32_t stamp_val;  // this launch's stamp (never 0)
   PoolConst pc;
   int32_t n;
   int32_t row0;
@@ -296,6 +308,8 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
         }
         // the reference only reaches the check on the Step branch, not on an auto-reset
         if (!ok && !(rec.state >= episode_len(a.pc.seed, eid))) a.err->action_check = 1u;
+        // (a forced reset of an env named twice writes the same record twice: harmless, not flagged)
+        if (a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;
       }
       const int32_t L = episode_len(a.pc.seed, eid);
       o = step_env(rec, eid, L, a.force_reset != 0, action_num, a.pc.max_episode_steps);
@@ -336,11 +350,20 @@ struct RolloutArgs {
   EnvRec* env;
   StatPtrs stats;
   RingLayout ring;
-  ErrWords* err;
+  ErrWords* err;       // error words, one per batch in flight: step t reports into err[(err0 + t) % err_depth]
+  int32_t err0, err_depth;
+  uint32_t* stamp;     // [N] per-env launch stamps (checked once per launch: env_id is the same every step)
+  uint32_t stamp_val;
   PoolConst pc;
   int32_t slot0;
   int32_t T;
 };
+
+__device__ __forceinline__ ErrWords* rollout_err(const RolloutArgs& a, int t) {
+  int w = a.err0 + t;
+  w -= (w >= a.err_depth) ? a.err_depth : 0;  // T <= ring depth <= err_depth
+  return a.err + w;
+}
 
 template <int S_CT>
 __global__ __launch_bounds__(kBlock) void dummy_rollout_sp(RolloutArgs a) {
@@ -364,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void dummy_rollout_sp(RolloutArgs a) {
   const bool in_range = valid && local >= 0 && local < N;
   EnvRec rec{0, 0};
   if (in_range) rec = a.env[local];
+  if (in_range && stamp_seen(a.stamp, local, a.stamp_val)) rollout_err(a, 0)->dup_env = 1u;
   const int32_t L = episode_len(a.pc.seed, eid);
 
   for (int t = 0; t < a.T; ++t) {
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void dummy_rollout_sp(RolloutArgs a) {
       if (in_range) {
         bool will_reset = rec.state >= L;
         bool ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
-        if (!ok && !will_reset) a.err->action_check = 1u;
+        if (!ok && !will_reset) rollout_err(a, t)->action_check = 1u;
         o = step_env(rec, eid, L, false, (penv == eid) ? 1 : 0, a.pc.max_episode_steps);
         if (o.done) {
           a.stats.fin_return[local] = a.stats.ep_return[local];
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void dummy_rollout_sp(RolloutArgs a) {
         }
         if (o.elapsed == 0) a.stats.ep_return[local] = 0.f;
       } else {
-        a.err->env_id_range = 1u;
+        rollout_err(a, t)->env_id_range = 1u;
         o.env_id = eid; o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0;
       }
       s.env_id[tid] = o.env_id;

@@ -3,65 +3,77 @@
 
 namespace epk_mp {
 
+// Fills and launches mp_step_fused for `cnt` items. `sc` / `ticket_base` / epochs: see
+// dummy_mp_kernels.hpp. Shared by the pool path and ep_dummy_send_noalloc.
+int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt) {
+  a.n = cnt;
+  a.num_tiles = (cnt + epk::kMpTile - 1) / epk::kMpTile;
+  hipLaunchKernelGGL(epk::mp_step_fused, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return EP_OK;
+}
+
 int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-               int np_rows, bool force_reset) {
+               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked) {
   const uint64_t B = (uint64_t)p->B;
-  const bool count = !force_reset && np_rows > 0;
-  if (count) {
+  // one histogram per send (ParseAction scans the WHOLE players.env_id array for every env,
+  // env.h:128-132); its epoch is the stamp of the send's first launch
+  const uint32_t count_epoch = next_stamp(p);
+  if (!force_reset && np_rows > 0) {
     hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, p->stream, d_penv,
-                       np_rows, p->cfg.env_id_offset, p->N, p->d_mp_counts, 1);
+                       np_rows, p->cfg.env_id_offset, p->N, p->mp_sc.counts, count_epoch);
     HIP_TRY(hipGetLastError());
   }
   int i0 = 0;
+  size_t next_cut = 0;
   while (i0 < n) {
     uint64_t pos = p->alloc_count;
     uint64_t bi = pos / B;
     int slot = (int)(bi % (uint64_t)p->Q);
     int room = (int)(B - pos % B);
     int cnt = std::min(room, n - i0);
-    int row0 = (int)(pos % B);
-    epk::MpStepArgs a;
+    if (cuts) {
+      while (next_cut < cuts->size() && (*cuts)[next_cut] <= i0) ++next_cut;
+      if (next_cut < cuts->size()) cnt = std::min(cnt, (*cuts)[next_cut] - i0);
+    }
+    int row0 = (int)(pos % B);  // rows follow the allocation order: order == -1 whenever P > 1 (async_envpool.h:69,95)
+    SlotHost& sh = p->slots[slot];
+    const int word = err_index(p, bi);
+    epk::MpFusedArgs a;
     a.env_id = d_env_id + i0;
+    a.players_env_id = nullptr;
     a.list_action = d_la ? d_la + (size_t)i0 * 6 : nullptr;
-    a.counts = p->d_mp_counts;
+    a.sc = p->mp_sc;
+    a.count_epoch = count_epoch;
+    a.tile_epoch = next_stamp(p);
+    a.ticket_base = p->mp_ticket_total;
     a.env = p->d_env;
     a.stats = p->stats;
     a.slot = host_slot_ptrs(p, slot);
-    a.err = p->d_err + slot;
+    a.err = p->d_err + word;
+    a.stamp = (!host_checked && !force_reset) ? p->d_stamp : nullptr;
+    a.stamp_val = a.tile_epoch;
     a.pc = pool_const(p);
-    a.items = (epk::MpItem*)p->d_mp_items;
-    a.n = cnt;
+    a.slot_players = p->d_slot_players + slot;
+    a.host_players = p->d_host_players + word;
     a.row0 = row0;
     a.force_reset = force_reset ? 1 : 0;
     a.P = p->P;
-    hipLaunchKernelGGL(epk::mp_step, dim3((cnt + 255) / 256), dim3(256), 0, p->stream, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(epk::mp_scan, dim3(1), dim3(1024), 0, p->stream, (const epk::MpItem*)p->d_mp_items, cnt,
-                       p->d_mp_off, p->d_slot_players + slot, p->d_mp_base);
-    HIP_TRY(hipGetLastError());
-    epk::MpWriteArgs w;
-    w.items = (const epk::MpItem*)p->d_mp_items;
-    w.off = p->d_mp_off;
-    w.seg_base = p->d_mp_base;
-    w.slot = a.slot;
-    w.n = cnt;
-    w.S = p->S;
-    hipLaunchKernelGGL(epk::mp_write_players, dim3((cnt + 255) / 256), dim3(256), 0, p->stream, w);
-    HIP_TRY(hipGetLastError());
-    SlotHost& sh = p->slots[slot];
+    a.first_segment = sh.alloc_count == 0 ? 1 : 0;
+    {
+      TimedScope ts(p);
+      if (int rc = launch_fused(p->stream, a, cnt)) return rc;
+    }
+    p->mp_ticket_total += (uint32_t)a.num_tiles;
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
     sh.has_work = true;
+    sh.mp_word = word;
     sh.launch_id = ++p->launch_seq;
     if (int rc2 = mark_launch(p, sh.launch_id)) return rc2;
     p->alloc_count += cnt;
     i0 += cnt;
-  }
-  if (count) {
-    hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, p->stream, d_penv,
-                       np_rows, p->cfg.env_id_offset, p->N, p->d_mp_counts, 0);
-    HIP_TRY(hipGetLastError());
   }
   return EP_OK;
 }

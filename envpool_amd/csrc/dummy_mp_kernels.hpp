@@ -5,8 +5,19 @@
 //   num_players = state % (P-1) + 1   envpool2/dummy/dummy_envpool.h:139-140, 175-176
 //   (player_offset, shared_offset)    envpool2/core/state_buffer.h:85-88 — the reference bumps
 //       two packed counters with one fetch_add per env; here the shared offset is known on the
-//       host and the player offset is an exclusive prefix sum over the segment's num_players
-//       (wave64 shuffles + one LDS pass), added to the slot's running player count.
+//       host and the player offset is an exclusive prefix sum over the items' num_players.
+//
+// Two launches per send:
+//   mp_count_rows   players.env_id histogram (how many action rows each env owns, env.h:128-132)
+//                   into epoch-tagged 64-bit counters, so nothing has to be cleared afterwards;
+//   mp_step_fused   256 items per workgroup: env step + shared-row keys, a workgroup scan of
+//                   num_players, a single-pass decoupled look-back across workgroups (tile ids
+//                   from a ticket, so a tile only ever waits for tiles that already run), then
+//                   the workgroup writes its contiguous block of player rows cooperatively
+//                   (coalesced 4-byte stores per key, 16-byte stores for obs:raw). The last tile
+//                   leaves the slot's player total in a host-mapped word: recv needs no copy.
+// The scratch (counters, look-back granules, ticket) comes in as an argument: a pool brings its
+// own allocation, ep_dummy_send_noalloc the library's static array.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,145 +26,242 @@
 
 namespace epk {
 
-// players.env_id histogram: how many action rows each env owns in this send (env.h:128-132).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define EP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr int kMpTile = 256;
+constexpr uint32_t kMpFlagAgg = 1u, kMpFlagIncl = 2u;  // look-back granule: {epoch:32 | flag:2 | value:30}
+constexpr uint32_t kMpValueMask = 0x3fffffffu;
+constexpr unsigned kMpSpinLimit = 1u << 22;  // look-back polls before a tile gives up (and flags the batch)
+
+struct MpScratch {
+  unsigned long long* counts;  // [N] {epoch:32 | rows:32}
+  unsigned long long* tiles;   // [ceil(max items per launch / 256)] look-back granules
+  uint32_t* ticket;            // dynamic tile ids: tile = atomicAdd(ticket, 1) - ticket_base
+};
+
 __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int32_t env_off, int32_t N,
-                              int32_t* __restrict__ counts, int32_t delta_or_zero) {
+                              unsigned long long* counts, uint32_t epoch) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= np_rows) return;
   int32_t local = penv[j] - env_off;
   if (local < 0 || local >= N) return;  // rows of envs this pool does not own match nothing
-  if (delta_or_zero) atomicAdd(&counts[local], 1);
-  else counts[local] = 0;  // second pass: leave the histogram clean for the next send
+  unsigned long long* c = counts + local;
+  unsigned long long old = __hip_atomic_load(c, EP_RLX_AGENT), assumed;
+  do {
+    assumed = old;
+    const unsigned long long fresh = ((unsigned long long)epoch << 32) | 1ull;
+    const unsigned long long next = (uint32_t)(assumed >> 32) == epoch ? assumed + 1ull : fresh;
+    old = atomicCAS(c, assumed, next);
+  } while (old != assumed);
 }
 
-struct MpItem {  // per-item scratch carried from the step kernel to the player-row writer
-  int32_t eid, state, raw1, np;
-  int32_t done;
-};
-
-struct MpStepArgs {
-  const int32_t* env_id;
-  const double* list_action;
-  const int32_t* counts;
+struct MpFusedArgs {
+  const int32_t* env_id;          // [n] items of this launch
+  const int32_t* players_env_id;  // [n] single-player only (row i belongs to item i); else unused
+  const double* list_action;      // [n,6]; null on a forced reset
+  MpScratch sc;
+  uint32_t count_epoch;   // epoch of the histogram of this send
+  uint32_t tile_epoch;    // epoch of this launch's look-back granules (never 0)
+  uint32_t ticket_base;
   EnvRec* env;
-  StatPtrs stats;
+  StatPtrs stats;         // members may be null (no episode statistics kept)
   SlotPtrs slot;
   ErrWords* err;
+  uint32_t* stamp;        // see StepArgs; null = no duplicate check
+  uint32_t stamp_val;
   PoolConst pc;
-  MpItem* items;
-  int32_t n, row0, force_reset, P;
+  uint32_t* slot_players;  // device: player rows in the slot so far (read by tile 0 unless first_segment, written by the last tile)
+  uint32_t* host_players;  // host-visible copy written by the last tile (may be null)
+  int32_t n, row0, force_reset, P, first_segment, num_tiles;
 };
 
-// Step + shared-row keys (rows follow allocation order: order == -1 whenever P > 1,
-// async_envpool.h:69,95).
-__global__ __launch_bounds__(256) void mp_step(MpStepArgs a) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const int32_t eid = a.env_id[i];
-  const int32_t local = eid - a.pc.env_off;
-  MpItem it{eid, 0, 0, 1, 0};
-  StepOut o;
-  o.env_id = eid; o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0;
-  if (local >= 0 && local < a.pc.N) {
-    EnvRec rec = a.env[local];
-    const int32_t L = episode_len(a.pc.seed, eid);
-    int32_t action_num = 0;
-    if (!a.force_reset && !(rec.state >= L)) {
-      action_num = a.counts[local];
-      const double* la = a.list_action + (int64_t)i * 6;
-      bool ok = true;
+__device__ __forceinline__ int mp_find_item(const int32_t* excl, int r) {
+  // largest j in [0,256) with excl[j] <= r (valid items have np >= 1, so it owns row r)
+  int lo = 0, hi = kMpTile;
 #pragma unroll
-      for (int k = 1; k < 6; ++k) ok &= (la[0] == la[k]);
-      if (!ok) a.err->action_check = 1u;
-    }
-    o = step_env(rec, eid, L, a.force_reset != 0, action_num, a.pc.max_episode_steps);
-    a.env[local] = rec;
-    it.np = rec.state % (a.P - 1) + 1;
-    // return of the env = sum of its players' rewards, reward[k] = float(-k)
-    float r = -0.5f * (float)(it.np - 1) * (float)it.np;
-    float acc = (o.elapsed == 0) ? 0.f : a.stats.ep_return[local];
-    acc += r;
-    a.stats.ep_return[local] = acc;
-    if (o.done) {
-      a.stats.fin_return[local] = acc;
-      a.stats.fin_length[local] = o.elapsed;
-      a.stats.ep_count[local] += 1;
-    }
-  } else {
-    a.err->env_id_range = 1u;
+  for (int s = 0; s < 8; ++s) {
+    const int mid = (lo + hi) >> 1;
+    if (excl[mid] <= r) lo = mid; else hi = mid;
   }
-  it.state = o.state; it.raw1 = o.raw1; it.done = o.done;
-  a.items[i] = it;
-  const int64_t r = (int64_t)a.row0 + i;
-  a.slot.env_id[r] = o.env_id;
-  a.slot.elapsed[r] = o.elapsed;
-  a.slot.step_type[r] = o.step_type;
-  a.slot.done[r] = o.done;
-  a.slot.trunc[r] = o.trunc;
+  return lo;
 }
 
-// Exclusive prefix sum of items[].np over one segment (single workgroup, wave64 shuffles),
-// plus the hand-over of the slot's running player count.
-__global__ __launch_bounds__(1024) void mp_scan(const MpItem* __restrict__ items, int n,
-                                                int32_t* __restrict__ off, uint32_t* slot_players,
-                                                int32_t* seg_base) {
-  __shared__ int32_t wave_tot[16];
-  __shared__ int32_t carry;
+__global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
+  __shared__ int32_t s_excl[kMpTile + 1];
+  __shared__ int32_t s_eid[kMpTile], s_state[kMpTile], s_raw1[kMpTile];
+  __shared__ uint8_t s_done[kMpTile];
+  __shared__ int32_t s_wave_tot[kMpTile / 64];
+  __shared__ uint32_t s_tile, s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
+  if (tid == 0) s_tile = atomicAdd(a.sc.ticket, 1u) - a.ticket_base;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    int i = base + tid;
-    int v = i < n ? items[i].np : 0;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
+  const int tile = (int)s_tile;
+  const int64_t i = (int64_t)tile * kMpTile + tid;
+  const bool valid = tile < a.num_tiles && i < a.n;
+
+  // ---- env step + shared-row keys -------------------------------------------------------
+  int np = 0;
+  if (valid) {
+    const int32_t eid = a.env_id[i];
+    const int32_t local = eid - a.pc.env_off;
+    StepOut o;
+    o.env_id = eid; o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0;
+    np = 1;
+    if (local >= 0 && local < a.pc.N) {
+      EnvRec rec = a.env[local];
+      const int32_t L = episode_len(a.pc.seed, eid);
+      int32_t action_num = 0;
+      if (!a.force_reset && !(rec.state >= L)) {
+        if (a.P <= 1) {
+          action_num = a.players_env_id[i] == eid ? 1 : 0;  // env.h:115-123 + dummy_envpool.h:179-184
+        } else {
+          const unsigned long long c = a.sc.counts[local];
+          action_num = (uint32_t)(c >> 32) == a.count_epoch ? (int32_t)(uint32_t)c : 0;
+        }
+        const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
+        const double2 v0 = la[0], v1 = la[1], v2 = la[2];
+        const bool ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        if (!ok) a.err->action_check = 1u;
+      }
+      if (!a.force_reset && a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;
+      o = step_env(rec, eid, L, a.force_reset != 0, action_num, a.pc.max_episode_steps);
+      a.env[local] = rec;
+      np = a.P <= 1 ? 1 : rec.state % (a.P - 1) + 1;
+      if (a.stats.ep_return) {
+        // return of the env = sum of its players' rewards, reward[k] = float(-k)
+        const float r = -0.5f * (float)(np - 1) * (float)np;
+        float acc = (o.elapsed == 0) ? 0.f : a.stats.ep_return[local];
+        acc += r;
+        a.stats.ep_return[local] = acc;
+        if (o.done) {
+          a.stats.fin_return[local] = acc;
+          a.stats.fin_length[local] = o.elapsed;
+          a.stats.ep_count[local] += 1;
+        }
+      }
+    } else {
+      a.err->env_id_range = 1u;
     }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int wprefix = 0;
-    for (int w = 0; w < wave; ++w) wprefix += wave_tot[w];
-    int c = carry;
-    if (i < n) off[i] = c + wprefix + incl - v;
-    __syncthreads();
-    if (tid == 1023) carry = c + wprefix + incl;
-    __syncthreads();
+    s_eid[tid] = eid;
+    s_state[tid] = o.state;
+    s_raw1[tid] = o.raw1;
+    s_done[tid] = o.done;
+    const int64_t r = (int64_t)a.row0 + i;
+    a.slot.env_id[r] = o.env_id;
+    a.slot.elapsed[r] = o.elapsed;
+    a.slot.step_type[r] = o.step_type;
+    a.slot.done[r] = o.done;
+    a.slot.trunc[r] = o.trunc;
   }
-  if (tid == 0) {
-    uint32_t b = *slot_players;
-    *seg_base = (int32_t)b;
-    *slot_players = b + (uint32_t)carry;
-  }
-}
 
-struct MpWriteArgs {
-  const MpItem* items;
-  const int32_t* off;
-  const int32_t* seg_base;
-  SlotPtrs slot;
-  int32_t n, S;
-};
-
-// Player-row keys. One thread per item; an item owns np <= P consecutive rows.
-__global__ __launch_bounds__(256) void mp_write_players(MpWriteArgs a) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const MpItem it = a.items[i];
-  const int64_t r0 = (int64_t)(*a.seg_base) + a.off[i];
-  for (int k = 0; k < it.np; ++k) {
-    const int64_t r = r0 + k;
-    a.slot.penv[r] = it.eid;                              // env.h:210-213
-    a.slot.pid[r] = k;                                    // dummy_envpool.h:148/:200
-    a.slot.pdone[r] = (uint8_t)it.done;                   // :149/:201
-    a.slot.reward[r] = (float)(-k);                       // :152/:204
-    a.slot.discount[r] = (k == 0 && !it.done) ? 1.f : 0.f;  // env.h:202 hits element 0 only
-    int32_t* row = a.slot.raw + r * a.S;
-    row[0] = it.state;
-    row[1] = it.raw1;
-    for (int c = 2; c < a.S; ++c) row[c] = 0;
+  // ---- workgroup exclusive scan of np -----------------------------------------------------
+  int incl = np;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
   }
+  if (lane == 63) s_wave_tot[wave] = incl;
+  __syncthreads();
+  int wprefix = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kMpTile / 64; ++w) {
+    const int t = s_wave_tot[w];
+    wprefix += w < wave ? t : 0;
+    total += t;
+  }
+  s_excl[tid] = wprefix + incl - np;
+  if (tid == 0) s_excl[kMpTile] = total;
+
+  // ---- decoupled look-back (wave 0): player rows of all earlier tiles of this launch ---------
+  if (wave == 0 && tile < a.num_tiles) {
+    gu64* tiles = (gu64*)a.sc.tiles;
+    const unsigned long long tag = (unsigned long long)a.tile_epoch << 32;
+    uint32_t base = 0;
+    if (tile == 0) {
+      base = a.first_segment ? 0u : *a.slot_players;  // rows earlier sends left in this batch
+      if (lane == 0)
+        __hip_atomic_store(tiles, tag | ((unsigned long long)kMpFlagIncl << 30) | (base + (uint32_t)total), EP_RLX_AGENT);
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(tiles + tile, tag | ((unsigned long long)kMpFlagAgg << 30) | (uint32_t)total, EP_RLX_AGENT);
+      int look = tile - 1;  // nearest tile not accounted for yet
+      unsigned spins = 0;
+      for (;;) {
+        const int t = look - lane;
+        uint32_t flag = 0, val = 0;
+        if (t >= 0) {
+          const unsigned long long g = __hip_atomic_load(tiles + t, EP_RLX_AGENT);
+          if ((uint32_t)(g >> 32) == a.tile_epoch) { flag = (uint32_t)(g >> 30) & 3u; val = (uint32_t)g & kMpValueMask; }
+        }
+        const unsigned long long m_incl = __ballot(t >= 0 && flag == kMpFlagIncl);
+        const unsigned long long m_wait = __ballot(t >= 0 && flag == 0u);
+        const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
+        const int first_wait = m_wait ? __builtin_ctzll(m_wait) : 64;
+        if (first_wait < first_incl) {  // a tile in front of the nearest inclusive one has not published yet
+          if (++spins > kMpSpinLimit) {  // cannot happen with ticket order; never hang the GPU on a bug
+            if (lane == 0) a.err->env_id_range = 1u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        uint32_t part = (t >= 0 && lane <= first_incl) ? val : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        base += part;
+        if (first_incl < 64 || look < 64) break;
+        look -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(tiles + tile, tag | ((unsigned long long)kMpFlagIncl << 30) | (base + (uint32_t)total), EP_RLX_AGENT);
+    }
+    if (lane == 0) {
+      s_base = base;
+      if (tile == a.num_tiles - 1) {
+        *a.slot_players = base + (uint32_t)total;
+        if (a.host_players) *a.host_players = base + (uint32_t)total;
+      }
+    }
+  }
+  __syncthreads();
+  if (tile >= a.num_tiles) return;
+  const int64_t R0 = (int64_t)s_base;
+
+  // ---- player rows: the tile's `total` rows are contiguous from R0 ---------------------------
+  for (int r = tid; r < total; r += kMpTile) {
+    const int j = mp_find_item(s_excl, r);
+    const int k = r - s_excl[j];
+    const int64_t R = R0 + r;
+    const uint8_t done = s_done[j];
+    a.slot.penv[R] = s_eid[j];                               // env.h:210-213
+    a.slot.pid[R] = k;                                       // dummy_envpool.h:148/:200
+    a.slot.pdone[R] = done;                                  // :149/:201
+    a.slot.reward[R] = (float)(-k);                          // :152/:204
+    a.slot.discount[R] = (k == 0 && !done) ? 1.f : 0.f;      // env.h:202 hits element 0 only
+  }
+  // obs:raw rows {state, raw1, 0, ...}: scalar stores up to the first 16-byte boundary, 16-byte
+  // stores in the middle
+  const int S = a.pc.S;
+  const int64_t E0 = R0 * S;
+  const int nelem = total * S;
+  int32_t* const raw = a.slot.raw + E0;
+  auto value = [&](int e) -> int32_t {
+    const int r = e / S, c = e - r * S;
+    if (c >= 2) return 0;
+    const int j = mp_find_item(s_excl, r);
+    return c == 0 ? s_state[j] : s_raw1[j];
+  };
+  const int lead = min(nelem, (int)((4 - (E0 & 3)) & 3));
+  if (tid < lead) raw[tid] = value(tid);
+  const int nvec = (nelem - lead) >> 2;
+  for (int q = tid; q < nvec; q += kMpTile) {
+    const int e = lead + (q << 2);
+    *reinterpret_cast<int4*>(raw + e) = make_int4(value(e), value(e + 1), value(e + 2), value(e + 3));
+  }
+  const int tail0 = lead + (nvec << 2);
+  if (tid < nelem - tail0) raw[tail0 + tid] = value(tail0 + tid);
 }
 
 }  // namespace epk

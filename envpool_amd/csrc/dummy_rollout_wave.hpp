@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_wave(RolloutArgs a) {
   const bool in_range = local >= 0 && local < a.pc.N;
   EnvRec rec{0, 0};
   if (in_range) rec = a.env[local];
+  const bool dup = in_range && stamp_seen(a.stamp, local, a.stamp_val);
   const int32_t L = episode_len(a.pc.seed, eid);
   const int32_t max_steps = a.pc.max_episode_steps;
 
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_wave(RolloutArgs a) {
 #pragma unroll
   for (int d = 0; d < D; ++d) fetch(d, d);
 
-  // rare-path accumulators, flushed after the loop
-  bool bad_action = false;
+  // rare-path accumulators, flushed after the loop (first_bad: the first step whose self-check failed)
+  int32_t first_bad = -1;
   int32_t fin_len = 0, fin_cnt = 0;
 
   char* const ring = a.ring.ring;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_wave(RolloutArgs a) {
         asm volatile("" : "+v"(flags) : : "memory");
         fetch(d, t + D);  // keep D steps of loads in flight
         const bool will_reset = rec.state >= L;
-        bad_action |= ((flags & 1) == 0) & (!will_reset) & in_range;
+        const bool bad = ((flags & 1) == 0) & (!will_reset) & in_range;
+        first_bad = (bad & (first_bad < 0)) ? t : first_bad;
         StepOut o = step_env(rec, eid, L, false, (flags >> 1) & 1, max_steps);
         if (!in_range) { o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0; }
         if (o.done) { fin_len = o.elapsed; fin_cnt += 1; }
@@ -189,9 +191,10 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_wave(RolloutArgs a) {
       a.stats.ep_count[local] += fin_cnt;
     }
   } else {
-    a.err->env_id_range = 1u;
+    rollout_err(a, 0)->env_id_range = 1u;
   }
-  if (bad_action) a.err->action_check = 1u;
+  if (dup) rollout_err(a, 0)->dup_env = 1u;
+  if (first_bad >= 0) rollout_err(a, first_bad)->action_check = 1u;  // reported with the step that failed
 }
 
 // ---------------------------------------------------------------------------------------
@@ -278,7 +281,9 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
   const bool in_range = local >= 0 && local < a.pc.N;
   EnvRec rec{0, 0};
   if (in_range) rec = a.env[local];
-  asm volatile("" : "+v"(rec.state), "+v"(rec.cur_step) : : "memory");
+  uint32_t dup_w = (in_range && stamp_seen(a.stamp, local, a.stamp_val)) ? 1u : 0u;
+  asm volatile("" : "+v"(rec.state), "+v"(rec.cur_step), "+v"(dup_w) : : "memory");
+  const bool dup = dup_w != 0;
   const int32_t L = episode_len(a.pc.seed, eid);
   const int32_t max_steps = a.pc.max_episode_steps;
 
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
     dma4(pe_lane + (int64_t)tc * pe_step, l + kRingLa);
   };
 
-  bool bad_action = false;
+  int32_t first_bad = -1;  // the first step whose self-check failed for this lane
   int32_t fin_len = 0, fin_cnt = 0;
   char* const ring = a.ring.ring;
   const uint64_t stride = a.ring.stride;
@@ -321,7 +326,8 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
     asm volatile("" : "+v"(flags) : : "memory");
     fetch(d, t + D);
     const bool will_reset = rec.state >= L;
-    bad_action |= ((flags & 1) == 0) & (!will_reset) & in_range;
+    const bool bad = ((flags & 1) == 0) & (!will_reset) & in_range;
+    first_bad = (bad & (first_bad < 0)) ? t : first_bad;
     StepOut o = step_env(rec, eid, L, false, (flags >> 1) & 1, max_steps);
     if (!in_range) { o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0; }
     if (o.done) { fin_len = o.elapsed; fin_cnt += 1; }
@@ -385,9 +391,10 @@ __global__ __launch_bounds__(kWave) void dummy_rollout_dma(RolloutArgs a) {
       a.stats.ep_count[local] += fin_cnt;
     }
   } else {
-    a.err->env_id_range = 1u;
+    rollout_err(a, 0)->env_id_range = 1u;
   }
-  if (bad_action) a.err->action_check = 1u;
+  if (dup) rollout_err(a, 0)->dup_env = 1u;
+  if (first_bad >= 0) rollout_err(a, first_bad)->action_check = 1u;  // reported with the step that failed
 }
 
 }  // namespace epk

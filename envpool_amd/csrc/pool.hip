@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +49,7 @@ struct SlotHost {
   std::vector<std::pair<int64_t, int64_t>> written;  // shared rows written, [a,b)
   bool has_work = false;
   uint64_t launch_id = 0;  // id of the last launch that wrote this slot
+  int mp_word = -1;        // multi-player pools: index of the player-total word of this batch
   void* host_blk = nullptr;  // direct host mode: the kernels wrote this batch straight into a pinned block, not the ring
 };
 
@@ -67,17 +70,25 @@ struct ep_pool {
   size_t key_off[11]{};
   size_t key_rowbytes[11]{};
   bool key_is_player[11]{};
-  // multi-player scratch
-  int32_t* d_mp_counts = nullptr;   // [N] rows of players.env_id per env in the current send
-  int32_t* d_mp_np = nullptr;       // [cap] players per item
-  int32_t* d_mp_off = nullptr;      // [cap] exclusive scan
-  void* d_mp_items = nullptr;       // [cap] epk::MpItem
-  int32_t* d_mp_base = nullptr;     // [1] player rows already in the slot before this segment
-  uint32_t* d_slot_players = nullptr;  // [Q] player_offset of each slot (device counter)
-  uint32_t* h_slot_players = nullptr;  // pinned mirror
-  // error words (host-mapped)
-  epk::ErrWords* h_err = nullptr;  // [Q]
+  // multi-player scratch (dummy_mp_kernels.hpp)
+  epk::MpScratch mp_sc{};              // histogram counters [N], look-back granules, ticket
+  uint32_t mp_ticket_total = 0;        // tiles launched so far (the ticket counter never goes back)
+  uint32_t* d_slot_players = nullptr;  // [Q] player_offset of each slot (device running total)
+  uint32_t* h_slot_players = nullptr;  // [EQ] host-mapped: final player_offset per batch generation
+  uint32_t* d_host_players = nullptr;  // device alias of h_slot_players
+  // error words (host-mapped), one per batch GENERATION: batch bi reports into word bi % EQ with
+  // EQ = 2Q, so a batch handed out by ep_pool_recv_on_stream (whose word is only looked at by the
+  // next ep_pool_sync) keeps its word while its ring slot is already being refilled
+  int EQ = 0;
+  epk::ErrWords* h_err = nullptr;  // [EQ]
   epk::ErrWords* d_err = nullptr;  // device alias of h_err
+  std::vector<uint64_t> deferred_lid;  // [EQ] last launch that may write a deferred word
+  uint32_t sticky_err = 0;  // deferred words folded in when their index came round again: bit 0 action check, 1 id range, 2 duplicate env
+  // "written exactly once" (SURVEY.md §5): launch stamps per env
+  uint32_t* d_stamp = nullptr;    // [N] device-memory sends: checked by the kernels
+  std::vector<uint32_t> h_stamp;  // [N] host-memory sends: checked (and the send split) on the host
+  uint32_t h_stamp_seq = 0;
+  std::vector<int> seg_cuts;      // scratch of the host check
   // action staging for host sends
   int A = 0;
   size_t stage_bytes = 0;
@@ -95,10 +106,14 @@ struct ep_pool {
   uint64_t launch_seq = 0;       // launches enqueued on `stream`
   uint64_t completed_launch = 0; // highest launch id known to have finished (stream is in-order)
   hipEvent_t stats_ev = nullptr, consumer_ev = nullptr, recv_ev = nullptr;
-  std::vector<uint8_t> deferred_err;  // [Q] slots handed out by ep_pool_recv_on_stream, error word not looked at yet
+  std::vector<uint8_t> deferred_err;  // [EQ] batches handed out by ep_pool_recv_on_stream, error word not looked at yet
   std::vector<SlotHost> slots;
   std::mutex mu;
+  std::condition_variable cv;    // signalled when a send/reset has added rows (StateBuffer::Done -> sem_.signal)
+  int64_t recv_timeout_ms = -1;  // ep_pool_set_recv_timeout: < 0 wait like the reference, 0 never wait, > 0 bounded
   std::shared_ptr<HostBlocks> blocks;
+  const char* last_rollout_kernel = "";  // which rollout kernel the last ep_pool_rollout launched
+  bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
   int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
   bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
   // kernel timing
@@ -111,7 +126,7 @@ struct ep_pool {
 
 namespace epk_mp {
 int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-               int np_rows, bool force_reset);
+               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked);
 }
 
 namespace {
@@ -222,21 +237,85 @@ int mark_launch(ep_pool* p, uint64_t lid) {
 }
 
 // Blocks until launch `lid` has finished (the stream is in-order, so everything older has too).
-int wait_launch(ep_pool* p, uint64_t lid) {
+// `lk` (the caller's hold on p->mu), when given, is released around the wait: a consumer sitting
+// in recv must not keep other threads from sending (state_buffer.h:135-140 waits on a semaphore
+// with no lock held).
+int wait_launch(ep_pool* p, uint64_t lid, std::unique_lock<std::mutex>* lk = nullptr) {
   if (lid <= p->completed_launch) return EP_OK;
   while (!p->inflight.empty() && p->inflight.front().first < lid) {
     p->done_ev_pool.push_back(p->inflight.front().second);  // older launch: done once `lid` is
     p->inflight.pop_front();
   }
+  hipEvent_t ev = nullptr;
   if (!p->inflight.empty() && p->inflight.front().first == lid) {
-    HIP_TRY(hipEventSynchronize(p->inflight.front().second));
+    ev = p->inflight.front().second;
+    p->inflight.pop_front();
+  }
+  if (lk) lk->unlock();
+  const hipError_t e = ev ? hipEventSynchronize(ev) : hipStreamSynchronize(p->stream);
+  if (lk) lk->lock();
+  if (ev) p->done_ev_pool.push_back(ev);
+  if (e != hipSuccess) return fail(EP_ERR_HIP, "waiting for launch %llu failed: %s", (unsigned long long)lid, hipGetErrorString(e));
+  p->completed_launch = std::max(p->completed_launch, lid);
+  return EP_OK;
+}
+
+// hipStreamSynchronize(p->stream) with p->mu released; afterwards every launch enqueued before the
+// call is known to be finished.
+int sync_stream_unlocked(ep_pool* p, std::unique_lock<std::mutex>* lk) {
+  const uint64_t upto = p->launch_seq;
+  if (lk) lk->unlock();
+  const hipError_t e = hipStreamSynchronize(p->stream);
+  if (lk) lk->lock();
+  if (e != hipSuccess) return fail(EP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+  while (!p->inflight.empty() && p->inflight.front().first <= upto) {
     p->done_ev_pool.push_back(p->inflight.front().second);
     p->inflight.pop_front();
-  } else {
-    HIP_TRY(hipStreamSynchronize(p->stream));
   }
-  p->completed_launch = lid;
+  p->completed_launch = std::max(p->completed_launch, upto);
   return EP_OK;
+}
+
+// ---- error words ----------------------------------------------------------------------------
+int err_index(ep_pool* p, uint64_t bi) { return (int)(bi % (uint64_t)p->EQ); }
+
+uint32_t take_err_bits(ep_pool* p, int w) {  // reads and clears word w
+  epk::ErrWords& e = p->h_err[w];
+  const uint32_t bits = (e.action_check ? 1u : 0u) | (e.env_id_range ? 2u : 0u) | (e.dup_env ? 4u : 0u);
+  e.action_check = 0;
+  e.env_id_range = 0;
+  e.dup_env = 0;
+  p->deferred_err[w] = 0;
+  return bits;
+}
+
+int status_of_err_bits(uint32_t bits, const char* what) {
+  if (bits & 1u)
+    return fail(EP_ERR_ACTION_CHECK,
+                "%s: Dummy action self-check failed: list_action lanes differ (the reference aborts here, "
+                "dummy_envpool.h:189-192)", what);
+  if (bits & 2u) return fail(EP_ERR_ACTION_CHECK, "%s: an env_id in the sent batch is outside this pool's shard", what);
+  if (bits & 4u)
+    return fail(EP_ERR_DUP_ENV,
+                "%s: a device-memory send (or rollout) named an env twice; its two items were stepped "
+                "concurrently and the rows of that env are not the reference's", what);
+  return EP_OK;
+}
+
+// Batch `bi` is about to get its first rows: if its error word still belongs to the batch 2Q
+// earlier (handed out by ep_pool_recv_on_stream and never looked at), fold that one into the
+// pool's sticky flags, which the next ep_pool_sync reports.
+int claim_err_word(ep_pool* p, uint64_t bi) {
+  const int w = err_index(p, bi);
+  if (!p->deferred_err[w]) return EP_OK;
+  if (int rc = wait_launch(p, p->deferred_lid[w])) return rc;
+  p->sticky_err |= take_err_bits(p, w);
+  return EP_OK;
+}
+
+uint32_t next_stamp(ep_pool* p) {  // stamp of the launch about to be enqueued: its id, never 0
+  const uint32_t v = (uint32_t)(p->launch_seq + 1);
+  return v ? v : 1u;
 }
 
 // Launch the single-player kernel for items [i0, i0+n) of one send/reset that land in `slot`
@@ -244,8 +323,8 @@ int wait_launch(ep_pool* p, uint64_t lid) {
 // `done_ev`, when given, rides on the kernel's own dispatch packet as its completion event (no
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-              int slot, int row0, bool force_reset, hipEvent_t done_ev = nullptr, char* out_base = nullptr,
-              hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
+              int slot, int err_w, int row0, bool force_reset, bool check_dup, hipEvent_t done_ev = nullptr,
+              char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
@@ -255,7 +334,9 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.env = p->d_env;
   a.stats = p->stats;
   a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
-  a.err = p->d_err + slot;
+  a.err = p->d_err + err_w;
+  a.stamp = check_dup ? p->d_stamp : nullptr;
+  a.stamp_val = next_stamp(p);
   a.pc = pool_const(p);
   a.n = n;
   a.row0 = row0;
@@ -274,12 +355,17 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
 
 // Common tail of send/reset once the action arrays are on the device.
 // `n` items; multi-player: `np_rows` rows in players.env_id.
+// `cuts`: positions (ascending, in (0, n)) at which the items must be split into separate launches
+// because an env shows up again (host-validated sends); null for device-memory sends, whose
+// kernels check the per-env launch stamps instead.
 // `row_base` / `out_base`: direct host mode sends one batch as several calls (row_base = rows
 // already sent) whose kernels write into a pinned host block instead of the ring slot.
 int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
-                   int n, int np_rows, bool force_reset, int row_base = 0, char* out_base = nullptr,
-                   hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
+                   int n, int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked,
+                   int row_base = 0, char* out_base = nullptr, hipStream_t st = nullptr,
+                   const uint32_t* la_ok = nullptr) {
   if (n == 0) return EP_OK;
+  if (p->poisoned) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
   const uint64_t B = (uint64_t)p->B;
   // ring capacity check for every batch this call touches
   uint64_t first_bi = p->alloc_count / B, last_bi = (p->alloc_count + (uint64_t)n - 1) / B;
@@ -288,26 +374,38 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
       return fail(EP_ERR_RING_FULL,
                   "StateBuffer ring full: %d un-received batches (ring_depth=%d); call recv", p->Q,
                   p->Q);
+  for (uint64_t bi = first_bi; bi <= last_bi; ++bi)
+    if (p->slots[bi % (uint64_t)p->Q].alloc_count == 0)
+      if (int rc = claim_err_word(p, bi)) return rc;
   if (p->is_sync) p->stepping_env_num += n;  // async_envpool.h:73-75 / :185-187
 
+  int rc = EP_OK;
   if (p->P > 1) {
-    return epk_mp::enqueue_mp(p, d_env_id, d_penv, d_la, n, np_rows, force_reset);
+    rc = epk_mp::enqueue_mp(p, d_env_id, d_penv, d_la, n, np_rows, force_reset, cuts, host_checked);
+    p->cv.notify_all();
+    return rc;
   }
   int i0 = 0;
+  size_t next_cut = 0;
   while (i0 < n) {
     uint64_t pos = p->alloc_count;
     uint64_t bi = pos / B;
     int slot = (int)(bi % (uint64_t)p->Q);
     int room = (int)(B - pos % B);
     int cnt = std::min(room, n - i0);
+    if (cuts) {
+      while (next_cut < cuts->size() && (*cuts)[next_cut] <= i0) ++next_cut;
+      if (next_cut < cuts->size()) cnt = std::min(cnt, (*cuts)[next_cut] - i0);
+    }
     // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
     // otherwise rows follow the allocation order.
     int row0 = p->is_sync ? row_base + i0 : (int)(pos % B);
     hipEvent_t done_ev = take_done_event(p);
-    if (!done_ev) return fail(EP_ERR_HIP, "hipEventCreate failed");
-    int rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
-                       d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, row0, force_reset, done_ev, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
-    if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); return rc; }
+    if (!done_ev) { rc = fail(EP_ERR_HIP, "hipEventCreate failed"); break; }
+    rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
+                   d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0, force_reset,
+                   !host_checked && !force_reset, done_ev, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
+    if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); break; }
     SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
@@ -318,7 +416,9 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     p->alloc_count += cnt;
     i0 += cnt;
   }
-  return EP_OK;
+  if (rc != EP_OK && i0 > 0) p->poisoned = true;  // part of the send is on the stream, the queue counters are not the reference's any more
+  p->cv.notify_all();
+  return rc;
 }
 
 // Copies `bytes` of host action data into the next pinned staging slot and enqueues the H2D
@@ -379,12 +479,43 @@ void la_lanes_equal(const double* la, int cnt, uint32_t* bits) {
   }
 }
 
-int validate_ids_host(ep_pool* p, const int32_t* ids, int n) {
+// Host-memory ids: the shard range check, plus the rule that one launch steps an env at most
+// once. The reference's single worker steps an env named twice in one send twice, in order;
+// here `cuts` receives the positions at which the send is split into separate launches (in order
+// on one stream) so that the same happens. Ascending ids - the usual case - need one vectorised
+// pass; anything else goes through the per-env stamp array.
+int validate_ids_host(ep_pool* p, const int32_t* ids, int n, std::vector<int>* cuts) {
+  if (cuts) cuts->clear();
+  if (n <= 0) return EP_OK;
+  const uint32_t N = (uint32_t)p->N, off = (uint32_t)p->cfg.env_id_offset;
+  uint32_t bad = 0, not_inc = 0;
+  for (int i = 0; i < n; ++i) bad |= ((uint32_t)ids[i] - off >= N) ? 1u : 0u;
+  if (bad) {
+    for (int i = 0; i < n; ++i)
+      if ((uint32_t)ids[i] - off >= N)
+        return fail(EP_ERR_INVALID, "env_id %d at position %d is outside this pool's shard [%d, %d)",
+                    ids[i], i, p->cfg.env_id_offset, p->cfg.env_id_offset + p->N);
+  }
+  if (!cuts) return EP_OK;
+  for (int i = 1; i < n; ++i) not_inc |= (ids[i] <= ids[i - 1]) ? 1u : 0u;
+  if (!not_inc) return EP_OK;
+  if (p->h_stamp.empty()) p->h_stamp.assign((size_t)p->N, 0u);
+  auto fresh = [&]() -> uint32_t {
+    if (++p->h_stamp_seq == 0) {  // wrapped: forget every old stamp
+      std::fill(p->h_stamp.begin(), p->h_stamp.end(), 0u);
+      p->h_stamp_seq = 1;
+    }
+    return p->h_stamp_seq;
+  };
+  uint32_t cur = fresh();
+  uint32_t* st = p->h_stamp.data();
   for (int i = 0; i < n; ++i) {
-    int64_t local = (int64_t)ids[i] - p->cfg.env_id_offset;
-    if (local < 0 || local >= p->N)
-      return fail(EP_ERR_INVALID, "env_id %d at position %d is outside this pool's shard [%d, %d)",
-                  ids[i], i, p->cfg.env_id_offset, p->cfg.env_id_offset + p->N);
+    const uint32_t local = (uint32_t)ids[i] - off;
+    if (st[local] == cur) {
+      cuts->push_back(i);
+      cur = fresh();
+    }
+    st[local] = cur;
   }
   return EP_OK;
 }
@@ -474,23 +605,29 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   HIP_TRY(hipMemsetAsync(p->stats.ep_count, 0, 4 * (size_t)p->N, p->stream));
 
   // error words: host-mapped so that a (rare) failure is visible after the slot's event
-  HIP_TRY(hipHostMalloc((void**)&p->h_err, sizeof(epk::ErrWords) * (size_t)p->Q, hipHostMallocMapped));
-  memset(p->h_err, 0, sizeof(epk::ErrWords) * (size_t)p->Q);
+  p->EQ = 2 * p->Q;
+  HIP_TRY(hipHostMalloc((void**)&p->h_err, sizeof(epk::ErrWords) * (size_t)p->EQ, hipHostMallocMapped));
+  memset(p->h_err, 0, sizeof(epk::ErrWords) * (size_t)p->EQ);
   HIP_TRY(hipHostGetDevicePointer((void**)&p->d_err, p->h_err, 0));
+  HIP_TRY(hipMalloc((void**)&p->d_stamp, 4 * (size_t)p->N));
+  HIP_TRY(hipMemsetAsync(p->d_stamp, 0, 4 * (size_t)p->N, p->stream));
 
   // multi-player scratch
   if (p->P > 1) {
-    size_t cap = (size_t)p->N;
-    HIP_TRY(hipMalloc((void**)&p->d_mp_counts, 4 * (size_t)p->N));
-    HIP_TRY(hipMemsetAsync(p->d_mp_counts, 0, 4 * (size_t)p->N, p->stream));
-    HIP_TRY(hipMalloc((void**)&p->d_mp_np, 4 * cap));
-    HIP_TRY(hipMalloc((void**)&p->d_mp_off, 4 * cap));
-    HIP_TRY(hipMalloc((void**)&p->d_mp_items, sizeof(epk::MpItem) * cap));
-    HIP_TRY(hipMalloc((void**)&p->d_mp_base, 4));
+    if ((uint64_t)p->B * (uint64_t)p->P >= (1ull << 30))
+      return fail(EP_ERR_TOO_LARGE, "batch_size * max_num_players must stay below 2^30 player rows");
+    const size_t tiles = ((size_t)p->N + epk::kMpTile - 1) / epk::kMpTile;
+    HIP_TRY(hipMalloc((void**)&p->mp_sc.counts, 8 * (size_t)p->N));
+    HIP_TRY(hipMemsetAsync(p->mp_sc.counts, 0, 8 * (size_t)p->N, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->mp_sc.tiles, 8 * tiles));
+    HIP_TRY(hipMemsetAsync(p->mp_sc.tiles, 0, 8 * tiles, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->mp_sc.ticket, 4));
+    HIP_TRY(hipMemsetAsync(p->mp_sc.ticket, 0, 4, p->stream));
     HIP_TRY(hipMalloc((void**)&p->d_slot_players, 4 * (size_t)p->Q));
     HIP_TRY(hipMemsetAsync(p->d_slot_players, 0, 4 * (size_t)p->Q, p->stream));
-    HIP_TRY(hipHostMalloc((void**)&p->h_slot_players, 4 * (size_t)p->Q, hipHostMallocDefault));
-    memset(p->h_slot_players, 0, 4 * (size_t)p->Q);
+    HIP_TRY(hipHostMalloc((void**)&p->h_slot_players, 4 * (size_t)p->EQ, hipHostMallocMapped));
+    memset(p->h_slot_players, 0, 4 * (size_t)p->EQ);
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->d_host_players, p->h_slot_players, 0));
   }
 
   // action staging ring for host sends: env_id + players.env_id + list_action + 2 unused keys
@@ -509,7 +646,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->recv_ev, hipEventDisableTiming));
-  p->deferred_err.assign((size_t)p->Q, 0);
+  p->deferred_err.assign((size_t)p->EQ, 0);
+  p->deferred_lid.assign((size_t)p->EQ, 0);
   p->blocks = std::make_shared<HostBlocks>();
   p->blocks->bytes = p->slot_stride;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -533,15 +671,14 @@ int ep_pool_destroy(ep_pool* p) {
   for (auto e : p->stage_copied) (void)hipEventDestroy(e);
   (void)hipFree(p->d_ring);
   (void)hipFree(p->d_env);
+  (void)hipFree(p->d_stamp);
   (void)hipFree(p->stats.ep_return);
   (void)hipFree(p->stats.fin_return);
   (void)hipFree(p->stats.fin_length);
   (void)hipFree(p->stats.ep_count);
-  (void)hipFree(p->d_mp_counts);
-  (void)hipFree(p->d_mp_np);
-  (void)hipFree(p->d_mp_off);
-  (void)hipFree(p->d_mp_items);
-  (void)hipFree(p->d_mp_base);
+  (void)hipFree(p->mp_sc.counts);
+  (void)hipFree(p->mp_sc.tiles);
+  (void)hipFree(p->mp_sc.ticket);
   (void)hipFree(p->d_slot_players);
   if (p->h_slot_players) (void)hipHostFree(p->h_slot_players);
   if (p->h_err) (void)hipHostFree(p->h_err);
@@ -563,14 +700,15 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   if (rc) return rc;
   if (n == 0) return EP_OK;
   if (n > p->N) return fail(EP_ERR_INVALID, "reset of %d envs on a pool of %d", n, p->N);
-  if (mem == EP_MEM_DEVICE) return enqueue_slices(p, env_ids, nullptr, nullptr, n, 0, true);
-  if ((rc = validate_ids_host(p, env_ids, n))) return rc;
+  // (an env named twice in one reset is harmless: both items write the same record and the same rows)
+  if (mem == EP_MEM_DEVICE) return enqueue_slices(p, env_ids, nullptr, nullptr, n, 0, true, nullptr, false);
+  if ((rc = validate_ids_host(p, env_ids, n, nullptr))) return rc;
   int a = 0;
   if ((rc = stage_begin(p, &a))) return rc;
   char* h = p->h_stage + (size_t)a * p->stage_bytes;
   memcpy(h, env_ids, 4 * (size_t)n);
   if ((rc = stage_commit(p, a, 4 * (size_t)n))) return rc;
-  rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true);
+  rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true, nullptr, true);
   int rc2 = stage_release(p, a);
   return rc ? rc : rc2;
 }
@@ -593,11 +731,16 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   int rc = set_device(p);
   if (rc) return rc;
   if (n == 0) return EP_OK;
+  if (!arrays[0] || !arrays[1] || !arrays[2])
+    return fail(EP_ERR_INVALID, "env_id, players.env_id and list_action must not be NULL");
   if (mem == EP_MEM_DEVICE) {
+    if (((uintptr_t)arrays[0] & 3) || ((uintptr_t)arrays[1] & 3) || ((uintptr_t)arrays[2] & 7))
+      return fail(EP_ERR_INVALID, "device action arrays must be aligned to their element size");
     return enqueue_slices(p, (const int32_t*)arrays[0], (const int32_t*)arrays[1], (const double*)arrays[2],
-                          (int)n, (int)np_rows, false);
+                          (int)n, (int)np_rows, false, nullptr, false);
   }
-  if ((rc = validate_ids_host(p, (const int32_t*)arrays[0], (int)n))) return rc;
+  if ((rc = validate_ids_host(p, (const int32_t*)arrays[0], (int)n, &p->seg_cuts))) return rc;
+  const std::vector<int>* cuts = p->seg_cuts.empty() ? nullptr : &p->seg_cuts;
   int a = 0;
   if ((rc = stage_begin(p, &a))) return rc;
   char* h = p->h_stage + (size_t)a * p->stage_bytes;
@@ -612,7 +755,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   {
     const uint64_t pos = p->alloc_count;
     SlotHost& sh0 = p->slots[(int)((pos / (uint64_t)p->B) % (uint64_t)p->Q)];
-    if (p->direct_host && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= 4096 &&
+    if (p->direct_host && !cuts && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= 4096 &&
         sh0.alloc_count == 0 && !sh0.has_work && !sh0.host_blk && slot_free_for(p, pos / (uint64_t)p->B)) {
       void* blk = nullptr;
       if ((rc = epc::take_block(p->blocks, &blk))) return rc;
@@ -631,10 +774,18 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
           // the Step branch - is still decided by the kernel, which knows the env's state)
           la_lanes_equal((const double*)arrays[2] + 6 * (size_t)c0, cnt, (uint32_t*)(h + o2) + (c0 >> 5));
           rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
-                              c0, (char*)blk_dev, nullptr, (const uint32_t*)(sd + o2) + (c0 >> 5));
+                              nullptr, true, c0, (char*)blk_dev, nullptr, (const uint32_t*)(sd + o2) + (c0 >> 5));
         }
-        if (rc == EP_OK) sh0.host_blk = blk;
-        else epc::give_block(p->blocks, blk);
+        if (rc == EP_OK) {
+          sh0.host_blk = blk;
+        } else {
+          // kernels of earlier pieces may still be writing the block over PCIe: let them finish
+          // before it can be handed to anybody else; the queue counters of those pieces stand, so
+          // the pool refuses further work
+          (void)hipStreamSynchronize(p->stream);
+          p->poisoned = true;
+          epc::give_block(p->blocks, blk);
+        }
         int rc2 = stage_release(p, a);
         return rc ? rc : rc2;
       }
@@ -663,7 +814,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
     HIP_TRY(hipStreamWaitEvent(p->stream, p->stage_copied[a], 0));
   }
   rc = enqueue_slices(p, (const int32_t*)(d + o0), (const int32_t*)(d + o1), (const double*)(d + o2), (int)n,
-                      (int)np_rows, false);
+                      (int)np_rows, false, cuts, true);
   int rc2 = stage_release(p, a);
   return rc ? rc : rc2;
 }
@@ -683,6 +834,11 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
                 (long long)leading_dims[0], (long long)leading_dims[1], (long long)leading_dims[2]);
   if (step_stride_rows[0] != 0)
     return fail(EP_ERR_INVALID, "rollout keeps the env_id array fixed across steps (step stride 0)");
+  if (!arrays[0] || !arrays[1] || !arrays[2])
+    return fail(EP_ERR_INVALID, "env_id, players.env_id and list_action must not be NULL");
+  if (((uintptr_t)arrays[0] & 3) || ((uintptr_t)arrays[1] & 3) || ((uintptr_t)arrays[2] & 7))
+    return fail(EP_ERR_INVALID, "device action arrays must be aligned to their element size");
+  if (p->poisoned) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
   if (p->alloc_count % (uint64_t)p->B != 0)
     return fail(EP_ERR_INVALID, "rollout needs the queue on a batch boundary: receive the partial batch first");
   {
@@ -704,13 +860,24 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
   for (int k = 0; k < 11; ++k) a.ring.off[k] = (uint32_t)p->key_off[k];
   a.ring.depth = p->Q;
   uint64_t bi0 = p->alloc_count / (uint64_t)p->B;
+  for (int t = 0; t < T; ++t)
+    if ((rc = claim_err_word(p, bi0 + (uint64_t)t))) return rc;
   a.slot0 = (int)(bi0 % (uint64_t)p->Q);
-  a.err = p->d_err + a.slot0;  // errors of the whole rollout are reported with its first batch
+  a.err = p->d_err;  // a failed self-check is reported with the batch of the step that failed
+  a.err0 = err_index(p, bi0);
+  a.err_depth = p->EQ;
+  a.stamp = p->d_stamp;
+  a.stamp_val = next_stamp(p);
   a.pc = pool_const(p);
   a.T = T;
+  // the wave kernels load list_action as 16-byte pieces (LDS-DMA dwordx4 / double2): a view that is
+  // only 8-byte aligned, or a step stride that breaks the alignment, takes the generic kernel
+  const bool wide_ok = ((uintptr_t)arrays[2] & 15) == 0 && ((step_stride_rows[2] * 48) & 15) == 0;
+  p->last_rollout_kernel = "dummy_rollout_sp";
   {
     TimedScope ts(p);
-    if (p->S == 10 && p->N % epk::kWave == 0 && !p->force_generic) {
+    if (p->S == 10 && p->N % epk::kWave == 0 && !p->force_generic && wide_ok) {
+      p->last_rollout_kernel = p->rollout_variant == 1 ? "dummy_rollout_wave" : p->rollout_variant == 2 ? "dummy_rollout_dma<4>" : "dummy_rollout_dma<6>";
       // wave-autonomous software-pipelined loop (dummy_rollout_wave.hpp)
       const dim3 g(p->N / epk::kWave), b(epk::kWave);
       if (p->rollout_variant == 1) {
@@ -750,20 +917,42 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
 }  // extern "C"
 
 namespace {
+// StateBuffer::Wait (state_buffer.h:135-140): is the head batch complete? `additional` is the
+// credit AsyncEnvPool::Recv gives a sync pool whose outstanding env-steps do not fill a batch
+// (async_envpool.h:163-166).
+bool head_ready(ep_pool* p, int64_t* additional) {
+  const SlotHost& sh = p->slots[(size_t)(p->done_ptr % (uint64_t)p->Q)];
+  *additional = 0;
+  if (p->is_sync && p->stepping_env_num < p->B) *additional = p->B - p->stepping_env_num;
+  return (int64_t)sh.alloc_count + *additional == p->B;
+}
+
 // `consumer` != nullptr: stream-ordered form (ep_pool_recv_on_stream) - device views at once, the
-// consumer stream is made to wait instead of the host.
-int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = nullptr) {
+// consumer stream is made to wait instead of the host. `lk` holds p->mu; it is released around
+// every wait (for rows to be sent, for the GPU), so other threads can keep sending meanwhile -
+// the reference's consumer blocks on a semaphore with no lock held (state_buffer.h:135-140).
+int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mutex>& lk,
+                hipStream_t* consumer = nullptr) {
   int rc = EP_OK;
-  const int slot = (int)(p->done_ptr % (uint64_t)p->Q);
-  SlotHost& sh = p->slots[slot];
-  // async_envpool.h:163-166
   int64_t additional = 0;
-  if (p->is_sync && p->stepping_env_num < p->B) additional = p->B - p->stepping_env_num;
-  if ((int64_t)sh.alloc_count + additional != p->B)
-    return fail(EP_ERR_WOULD_BLOCK,
-                "recv would block forever: head batch has %llu of %d env-steps outstanding "
-                "(the reference deadlocks in StateBuffer::Wait here)",
-                (unsigned long long)sh.alloc_count, p->B);
+  if (!head_ready(p, &additional)) {
+    auto would_block = [&]() {
+      return fail(EP_ERR_WOULD_BLOCK,
+                  "recv would block: head batch has %llu of %d env-steps outstanding (the reference waits in "
+                  "StateBuffer::Wait here; ep_pool_set_recv_timeout chooses how long this library does)",
+                  (unsigned long long)p->slots[(size_t)(p->done_ptr % (uint64_t)p->Q)].alloc_count, p->B);
+    };
+    if (consumer || p->recv_timeout_ms == 0) return would_block();
+    auto pred = [&]() { return head_ready(p, &additional) || p->poisoned; };
+    if (p->recv_timeout_ms < 0) p->cv.wait(lk, pred);
+    else if (!p->cv.wait_for(lk, std::chrono::milliseconds(p->recv_timeout_ms), pred)) return would_block();
+    if (!head_ready(p, &additional)) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
+    if ((rc = set_device(p))) return rc;
+  }
+  const uint64_t bi = p->done_ptr;
+  const int slot = (int)(bi % (uint64_t)p->Q);
+  const int ew = err_index(p, bi);
+  SlotHost& sh = p->slots[slot];
   const uint32_t nrows = sh.shared_off;
   uint32_t nplayers = nrows;
   if (consumer && p->P > 1)
@@ -775,19 +964,14 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
     // the batch was written straight into a pinned block (direct host mode) but is wanted as
     // device views after all: bring it into its ring slot
     HIP_TRY(hipMemcpyAsync(p->d_ring + (size_t)slot * p->slot_stride, sh.host_blk, p->slot_stride, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if ((rc = sync_stream_unlocked(p, &lk))) return rc;
     epc::give_block(p->blocks, sh.host_blk);
     sh.host_blk = nullptr;
   }
   const bool one_sync = mem == EP_MEM_HOST && p->P == 1 && !consumer;
   if (sh.has_work && !consumer && !one_sync)
-    if ((rc = wait_launch(p, sh.launch_id))) return rc;
-  if (p->P > 1) {
-    HIP_TRY(hipMemcpyAsync(p->h_slot_players + slot, p->d_slot_players + slot, 4, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemsetAsync(p->d_slot_players + slot, 0, 4, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    nplayers = p->h_slot_players[slot];
-  }
+    if ((rc = wait_launch(p, sh.launch_id, &lk))) return rc;
+  if (p->P > 1) nplayers = sh.mp_word >= 0 ? p->h_slot_players[sh.mp_word] : 0;
   // rows inside [0, nrows) that no kernel wrote must read as zero (fresh zeroed StateBuffer,
   // array.h:77-81); only the reference's "several sync sends before one recv" corner gets here.
   if (p->P == 1 && nrows > 0) {
@@ -809,40 +993,28 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
     }
     if (cur < (int64_t)nrows)
       if ((rc = zero_rows(cur, nrows))) return rc;
-    if (any && !consumer && !one_sync) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (any && !consumer && !one_sync)
+      if ((rc = sync_stream_unlocked(p, &lk))) return rc;
   }
   int status = EP_OK;
   if (consumer) {
     // everything this batch needs is already on the step stream: another stream waits for it
-    // there, the step stream itself is in order anyway. The slot's error word is looked at later
+    // there, the step stream itself is in order anyway. The batch's error word is looked at later
     // (ep_pool_sync), when the kernels have run.
     if (*consumer != p->stream) {
       HIP_TRY(hipEventRecord(p->recv_ev, p->stream));
       HIP_TRY(hipStreamWaitEvent(*consumer, p->recv_ev, 0));
     }
-    p->deferred_err[slot] = 1;
+    p->deferred_err[ew] = 1;
+    p->deferred_lid[ew] = sh.launch_id;
     // nobody waits for launches on the host in this mode: retire their completion events here,
     // which also keeps the host from running more than about two rings ahead of the device
     while (p->inflight.size() > (size_t)(2 * p->Q + 8)) {
-      HIP_TRY(hipEventSynchronize(p->inflight.front().second));
-      p->completed_launch = std::max(p->completed_launch, p->inflight.front().first);
-      p->done_ev_pool.push_back(p->inflight.front().second);
-      p->inflight.pop_front();
+      const uint64_t lid = p->inflight.front().first;
+      if ((rc = wait_launch(p, lid, &lk))) return rc;
     }
   }
-  auto read_status = [&]() {  // the slot's error word, once its kernels have run
-    if (p->h_err[slot].action_check) {
-      status = fail(EP_ERR_ACTION_CHECK,
-                    "Dummy action self-check failed: list_action lanes differ (the reference aborts "
-                    "here, dummy_envpool.h:189-192)");
-    } else if (p->h_err[slot].env_id_range) {
-      status = fail(EP_ERR_ACTION_CHECK, "an env_id in the sent batch is outside this pool's shard");
-    }
-    p->h_err[slot].action_check = 0;
-    p->h_err[slot].env_id_range = 0;
-    p->deferred_err[slot] = 0;
-  };
-  if (!consumer && !one_sync) read_status();
+  if (!consumer && !one_sync) status = status_of_err_bits(take_err_bits(p, ew), "recv");
 
   memset(out, 0, sizeof(*out));
   out->num_keys = 12;
@@ -866,16 +1038,8 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
         if (r) HIP_TRY(hipMemcpyAsync((char*)blk + p->key_off[k], src + p->key_off[k], r * p->key_rowbytes[k], hipMemcpyDeviceToHost, p->stream));
       }
     }
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (one_sync) {
-      read_status();
-      // everything launched so far has finished: retire the completion events
-      while (!p->inflight.empty()) {
-        p->done_ev_pool.push_back(p->inflight.front().second);
-        p->inflight.pop_front();
-      }
-      p->completed_launch = p->launch_seq;
-    }
+    if ((rc = sync_stream_unlocked(p, &lk))) { epc::give_block(p->blocks, blk); return rc; }
+    if (one_sync) status = status_of_err_bits(take_err_bits(p, ew), "recv");
     out->owner = new HostBlockOwner{p->blocks, blk};
     base = (char*)blk;
   } else {
@@ -904,6 +1068,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, hipStream_t* consumer = 
   sh.shared_off = 0;
   sh.written.clear();
   sh.has_work = false;
+  sh.mp_word = -1;
   if (p->is_sync) p->stepping_env_num -= nrows;
   return status;
 }
@@ -913,33 +1078,45 @@ extern "C" {
 
 int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(p->mu);
+  std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
-  return recv_locked(p, mem, out);
+  return recv_locked(p, mem, out, lk);
 }
 
 int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(p->mu);
+  std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
   hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : p->stream;
-  return recv_locked(p, EP_MEM_DEVICE, out, &cs);
+  return recv_locked(p, EP_MEM_DEVICE, out, lk, &cs);
 }
 
 int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
-  std::lock_guard<std::mutex> lk(p->mu);
+  std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
   int status = EP_OK;
+  std::string first_msg;
   for (int i = 0; i < n; ++i) {
-    rc = recv_locked(p, mem, out + i);
-    if (rc == EP_ERR_ACTION_CHECK) { status = rc; continue; }
+    rc = recv_locked(p, mem, out + i, lk);
+    if (rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV) {  // the batch is there; keep going, report the first
+      if (status == EP_OK) { status = rc; first_msg = epc::g_last_error + " (batch " + std::to_string(i) + " of this call)"; }
+      continue;
+    }
     if (rc != EP_OK) return rc;
   }
+  if (status != EP_OK) epc::g_last_error = first_msg;
   return status;
+}
+
+int ep_pool_set_recv_timeout(ep_pool* p, int64_t milliseconds) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  p->recv_timeout_ms = milliseconds;
+  return EP_OK;
 }
 
 int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_length, int32_t* ep_count,
@@ -975,24 +1152,20 @@ int ep_batch_release(ep_batch* b) {
 
 int ep_pool_sync(ep_pool* p) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
-  std::lock_guard<std::mutex> lk(p->mu);
+  std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(p->copy_stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  lk.unlock();
+  hipError_t e = hipStreamSynchronize(p->copy_stream);
+  lk.lock();
+  if (e != hipSuccess) return fail(EP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+  if ((rc = sync_stream_unlocked(p, &lk))) return rc;
   // batches handed out by ep_pool_recv_on_stream: their error words are final now
-  bool bad = false;
-  for (int s = 0; s < p->Q; ++s) {
-    if (!p->deferred_err[s]) continue;
-    p->deferred_err[s] = 0;
-    if (p->h_err[s].action_check || p->h_err[s].env_id_range) bad = true;
-    p->h_err[s].action_check = 0;
-    p->h_err[s].env_id_range = 0;
-  }
-  if (bad)
-    return fail(EP_ERR_ACTION_CHECK, "a batch received with ep_pool_recv_on_stream failed the Dummy action self-check "
-                                     "or carried an env_id outside this pool's shard");
-  return EP_OK;
+  uint32_t bits = p->sticky_err;
+  p->sticky_err = 0;
+  for (int w = 0; w < p->EQ; ++w)
+    if (p->deferred_err[w]) bits |= take_err_bits(p, w);
+  return status_of_err_bits(bits, "a batch received with ep_pool_recv_on_stream");
 }
 
 int ep_pool_episode_stats(ep_pool* p, float* fin_return, int32_t* fin_length, int32_t* ep_count, int32_t mem) {

@@ -159,8 +159,9 @@ struct DummyPool {
       py::gil_scoped_release rel;
       rc = ep_pool_recv(pool, EP_MEM_HOST, &holder->batch);
     }
-    if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
-    std::string deferred = rc == EP_ERR_ACTION_CHECK ? ep_last_error() : "";
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    std::string deferred = batch_with_error ? ep_last_error() : "";
     std::vector<py::object> ret;
     ret.reserve(12);
     for (int k = 0; k < holder->batch.num_keys; ++k) {
@@ -182,8 +183,9 @@ struct DummyPool {
       py::gil_scoped_release rel;
       rc = ep_pool_recv(pool, EP_MEM_DEVICE, &b);
     }
-    if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
-    std::string deferred = rc == EP_ERR_ACTION_CHECK ? ep_last_error() : "";
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    std::string deferred = batch_with_error ? ep_last_error() : "";
     py::list out;
     for (int k = 0; k < b.num_keys; ++k) {
       if (b.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
@@ -258,6 +260,7 @@ struct DummyPool {
     epy::check(ep_pool_checkpoint_restore(pool, buf.data()));
   }
   void sync() { py::gil_scoped_release rel; epy::check(ep_pool_sync(pool)); }
+  void set_recv_timeout(int64_t ms) { epy::check(ep_pool_set_recv_timeout(pool, ms)); }
   uintptr_t stream() { return reinterpret_cast<uintptr_t>(ep_pool_stream(pool)); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
 };
@@ -292,6 +295,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_checkpoint_save", &DummyPool::checkpoint_save)
       .def("_checkpoint_restore", &DummyPool::checkpoint_restore)
       .def("_sync", &DummyPool::sync)
+      .def("_set_recv_timeout", &DummyPool::set_recv_timeout)
       .def("_stream", &DummyPool::stream)
       .def("_handle", &DummyPool::handle);
   m.def("device_count", []() { return ep_device_count(); });

@@ -38,7 +38,12 @@ enum {
                               state_buffer.h:111) */
   EP_ERR_ACTION_CHECK = 6, /* Dummy list_action lanes differ (reference: glog CHECK_EQ abort,
                               dummy_envpool.h:189-192) or env_id out of range */
-  EP_ERR_TOO_LARGE = 7
+  EP_ERR_TOO_LARGE = 7,
+  EP_ERR_DUP_ENV = 8       /* a device-memory send or rollout named an env twice in one launch: the two
+                              items raced, the rows of that env are not the reference's (the batch is
+                              still returned). Host-memory sends never report it: they are split on
+                              the host so that such an env is stepped twice IN ORDER, which is what
+                              the reference's worker does (async_envpool.h:116-129) */
 };
 
 /* ---- memory kinds --------------------------------------------------------- */
@@ -128,29 +133,42 @@ int ep_pool_reset(ep_pool* pool, const int32_t* env_ids, int32_t n, int32_t mem)
  * `leading_dims[k]` its leading dimension. Non-blocking: the step kernel is
  * enqueued on the pool's stream and the call returns. Host arrays are fully
  * consumed (copied to pinned staging) before return; device arrays must stay
- * untouched until the matching recv. An env_id may appear at most once in one
- * send: all items of a send are stepped concurrently (the reference's worker
- * threads race on such input as well). */
+ * untouched until the matching recv. An env named twice in one send is stepped
+ * twice, in order, like the reference's single worker does (host arrays: the
+ * send is split into launches at every repeat). Device arrays cannot be looked
+ * at by the host: there the items of one launch run concurrently, a repeat is
+ * detected by the kernels (per-env launch stamps) and the batch comes back with
+ * EP_ERR_DUP_ENV from recv. */
 int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
                  const int64_t* leading_dims, int32_t mem);
 
 /* Replaces: PyEnvPool::PyRecv -> AsyncEnvPool::Recv -> StateBufferQueue::Wait
  * -> StateBuffer::Wait (py_envpool.h:230-241, async_envpool.h:162-174,
  * state_buffer_queue.h:139-150, state_buffer.h:135-157). Blocks until the head
- * batch is complete, then describes it in `out`. EP_MEM_HOST: a fresh host
- * block holding every array (never reused; free with ep_batch_release).
- * EP_MEM_DEVICE: views into the ring slot, valid until ring_depth-1 further
- * batches have been received. Returns EP_ERR_WOULD_BLOCK instead of
- * deadlocking when fewer than batch_size env-steps are outstanding in async
- * mode, and EP_ERR_ACTION_CHECK when a step of this batch failed the Dummy
- * env's action self-check (the batch is still returned). */
+ * batch is complete - also for env-steps that other threads have yet to send,
+ * like StateBuffer::Wait; the pool's lock is not held while waiting, so sends
+ * from other threads go through - then describes it in `out`. EP_MEM_HOST: a
+ * fresh host block holding every array (never reused; free with
+ * ep_batch_release). EP_MEM_DEVICE: views into the ring slot, valid until
+ * ring_depth-1 further batches have been received. How long it waits for rows
+ * nobody has sent yet is set by ep_pool_set_recv_timeout (EP_ERR_WOULD_BLOCK
+ * when the time is up). Returns EP_ERR_ACTION_CHECK when a step of this batch
+ * failed the Dummy env's action self-check and EP_ERR_DUP_ENV for a repeated
+ * env in a device-memory send (the batch is still returned in both cases). */
 int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
+
+/* How long ep_pool_recv / ep_pool_recv_many wait for env-steps that have not been sent yet:
+ * < 0 (the default) for ever, as the reference does (a single-threaded caller that receives more
+ * than it sent deadlocks there and here); 0 never - EP_ERR_WOULD_BLOCK at once; > 0 that many
+ * milliseconds. Waiting for the GPU to finish rows that HAVE been sent is not affected. No
+ * counterpart in the reference. */
+int ep_pool_set_recv_timeout(ep_pool* pool, int64_t milliseconds);
 
 /* Stream-ordered ep_pool_recv(EP_MEM_DEVICE): describes the head batch as device views at once
  * and makes `consumer_stream` (a hipStream_t; NULL or ep_pool_stream() = the pool's own step
  * stream, which needs no wait at all) wait for the kernels that write it - the host never
  * blocks, so a policy that runs on the GPU sees one kernel launch per step instead of a launch
- * plus a host round trip. Same EP_ERR_WOULD_BLOCK rule as ep_pool_recv. Differences: single-player
+ * plus a host round trip. Never waits for unsent rows (EP_ERR_WOULD_BLOCK at once). Differences: single-player
  * pools only (EP_ERR_INVALID otherwise); an action self-check failure of such a batch is reported
  * by the next ep_pool_sync, not here; the views stay valid until ring_depth-1 further batches
  * have been received AND the consumer's reads are ordered before the step stream's later work

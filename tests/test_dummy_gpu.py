@@ -130,10 +130,10 @@ def test_rollout_reports_action_check():
   torch.cuda.synchronize()
   ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_penv.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr())
   capi._check(L.ep_pool_rollout(g.handle, T, 5, ptrs, (C.c_int64 * 5)(n, n, n, n, n), (C.c_int64 * 5)(0, n, n, 0, 0)))
-  g._recv(allow=(capi.EP_ERR_ACTION_CHECK,))
-  assert g.last_status == capi.EP_ERR_ACTION_CHECK
-  for _ in range(T - 1):
-    g._recv()
+  # the failure is reported with the batch of the step that failed (t = 2), not with the launch
+  for t in range(T):
+    g._recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+    assert (g.last_status == capi.EP_ERR_ACTION_CHECK) == (t == 2), t
 
 
 def test_async_mode_fifo_batches():
@@ -142,6 +142,7 @@ def test_async_mode_fifo_batches():
   from envpool_amd import capi
   rng = np.random.default_rng(3)
   g, o = _pair(num_envs=64, batch_size=24, seed=4)
+  g.set_recv_timeout(0)  # the default waits like StateBuffer::Wait; this test wants the refusal
   ids = np.arange(64, dtype=np.int32)
   g._reset(ids); o._reset(ids)
   outstanding = 64
@@ -235,7 +236,8 @@ def test_ring_full_and_action_check():
   assert g2.last_status == capi.EP_ERR_ACTION_CHECK
 
 
-@pytest.mark.parametrize("P,n,B", [(3, 4, 0), (2, 16, 0), (4, 300, 0), (3, 40, 16), (5, 2000, 512)])
+@pytest.mark.parametrize("P,n,B", [(3, 4, 0), (2, 16, 0), (4, 300, 0), (3, 40, 16), (5, 2000, 512), (3, 40000, 0),
+                                   (4, 70000, 30000)])
 def test_multiplayer_ragged_player_dim(P, n, B):
   """max_num_players > 1: player rows are a device prefix sum."""
   g, o = _pair(num_envs=n, batch_size=B, max_num_players=P, seed=2)

@@ -44,9 +44,8 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
       elif sync:
         sel = ids if rng.random() < 0.8 else rng.permutation(n).astype(np.int32)
       else:
-        uniq = np.unique(last_ids)  # (an env id at most once per send: two slices of one env in one send race in the
-        # reference's thread pool as well)
-        sel = rng.choice(uniq, size=int(rng.integers(1, len(uniq) + 1)), replace=False).astype(np.int32)
+        # with repeats: an env named twice in one send is stepped twice, in order
+        sel = rng.choice(last_ids, size=int(rng.integers(1, len(last_ids) + 1)), replace=True).astype(np.int32)
       if P > 1:
         break  # (multi-player sends are covered by the test-suite; here only reset + first batches)
       penv = sel + (rng.random(len(sel)) < 0.1).astype(np.int32)
