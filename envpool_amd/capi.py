@@ -42,7 +42,7 @@ SYMBOLS = [
   "ep_pool_checkpoint_bytes", "ep_pool_checkpoint_save", "ep_pool_checkpoint_restore",
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
   "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
-  "ep_last_error", "ep_version",
+  "ep_last_error", "ep_version", "ep_dummy_send_noalloc",
 ]
 
 _bound = None
@@ -76,6 +76,7 @@ def lib():
     L.ep_pool_stream.restype = vp
     L.ep_pool_set_timing.argtypes = [vp, i32]
     L.ep_pool_kernel_time_us.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), i32]
+    L.ep_dummy_send_noalloc.argtypes = [C.POINTER(DummyConfig), vp, i32, vp, i32, vp, vp, i32, C.POINTER(Array), i32, vp, vp]
     L.ep_last_error.restype = C.c_char_p
     L.ep_version.restype = C.c_char_p
     _bound = L

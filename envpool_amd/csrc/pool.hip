@@ -1219,6 +1219,133 @@ int ep_pool_checkpoint_restore(ep_pool* p, const void* buf) {
   return EP_OK;
 }
 
+// ---- ep_dummy_send_noalloc ------------------------------------------------------------------
+// The one entry point that allocates nothing (include/envpool_amd.h). Its kernels are the pool's
+// (mp_count_rows, mp_step_fused); their scratch - histogram counters, look-back granules, the tile
+// ticket - lives in this file-scope device array instead of a pool's allocation. `scratch` is a
+// host-side stand-in for the symbol, never a device address: the per-device address comes from
+// hipGetSymbolAddress, once per device, and only that pointer is handed to kernels and memsets.
+}  // extern "C"
+
+namespace {
+constexpr int kNoallocMaxEnvs = EP_NOALLOC_MAX_ENVS;
+constexpr int kNoallocMaxTiles = (kNoallocMaxEnvs + epk::kMpTile - 1) / epk::kMpTile;
+constexpr size_t kNoallocHead = 256;  // ticket word, padded
+constexpr size_t kNoallocTilesOff = kNoallocHead;
+constexpr size_t kNoallocCountsOff = kNoallocTilesOff + 8 * (size_t)kNoallocMaxTiles;
+constexpr size_t kNoallocBytes = kNoallocCountsOff + 8 * (size_t)kNoallocMaxEnvs;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
+namespace {
+constexpr int kNoallocMaxDevices = 64;
+std::mutex g_noalloc_mu;
+unsigned char* g_noalloc_ptr[kNoallocMaxDevices];  // per device: where ITS copy of `scratch` lives
+}  // namespace
+
+extern "C" {
+
+int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n, const int32_t* env_id,
+                          int32_t np_rows, const int32_t* players_env_id, const double* list_action,
+                          int32_t force_reset, const ep_array* out, int32_t n_out, ep_noalloc_result* result,
+                          void* stream) {
+  if (!cfg || !env_state || !out || !result || (n > 0 && !env_id))
+    return fail(EP_ERR_INVALID, "null argument");
+  const int N = cfg->num_envs, P = cfg->max_num_players, S = cfg->state_num;
+  if (N < 1 || P < 1 || S < 2) return fail(EP_ERR_INVALID, "bad config: num_envs %d, max_num_players %d, state_num %d", N, P, S);
+  if (N > kNoallocMaxEnvs)
+    return fail(EP_ERR_TOO_LARGE, "ep_dummy_send_noalloc handles at most %d envs (its scratch is a fixed static array); got num_envs = %d",
+                kNoallocMaxEnvs, N);
+  if (n < 0 || n > N) return fail(EP_ERR_TOO_LARGE, "n = %d outside [0, num_envs = %d]", n, N);
+  if (np_rows < 0 || (int64_t)np_rows > (int64_t)N * P)
+    return fail(EP_ERR_TOO_LARGE, "players.env_id has %d rows, more than num_envs * max_num_players", np_rows);
+  if ((int64_t)n * P >= (1ll << 30)) return fail(EP_ERR_TOO_LARGE, "n * max_num_players must stay below 2^30 player rows");
+  if (n_out != 12) return fail(EP_ERR_INVALID, "need the 12 output arrays in _state_keys order, got %d", n_out);
+  if (!force_reset && n > 0) {
+    if (!list_action) return fail(EP_ERR_INVALID, "list_action must not be NULL for a step");
+    if (P == 1 ? (!players_env_id || np_rows < n) : (np_rows > 0 && !players_env_id))
+      return fail(EP_ERR_INVALID, "players.env_id is NULL or too short");
+    if (((uintptr_t)list_action & 7) || ((uintptr_t)players_env_id & 3))
+      return fail(EP_ERR_INVALID, "device action arrays must be aligned to their element size");
+  }
+  for (int k = 0; k < 12; ++k) {
+    const int sk = kStateToSlot[k];
+    if (sk < 0) continue;  // obs:dyn has no array
+    const bool player = sk == 1 || sk == 4 || sk == 5 || sk >= 8;
+    const int64_t need = player ? (int64_t)n * P : (int64_t)n;
+    if (need > 0 && (!out[k].data || out[k].shape[0] < need))
+      return fail(EP_ERR_INVALID, "output array %d is NULL or holds %lld rows, need %lld (player-row keys: n * max_num_players)",
+                  k, (long long)out[k].shape[0], (long long)need);
+    if ((uintptr_t)out[k].data & (sk == 8 ? 15 : (size_t)kSlotElem[sk] - 1))
+      return fail(EP_ERR_INVALID, "output array %d is misaligned (obs:raw needs 16 bytes)", k);
+  }
+  if (cfg->device_id < 0 || cfg->device_id >= kNoallocMaxDevices) return fail(EP_ERR_INVALID, "device_id %d out of range", cfg->device_id);
+  HIP_TRY(hipSetDevice(cfg->device_id));
+  unsigned char* sc = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    if (!g_noalloc_ptr[cfg->device_id]) {  // set-up, once per device, with that device current
+      unsigned char* ptr = nullptr;
+      HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+      if (!ptr) return fail(EP_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+      g_noalloc_ptr[cfg->device_id] = ptr;
+    }
+    sc = g_noalloc_ptr[cfg->device_id];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // what must start at zero: the result words, the ticket and (multi-player steps) the histogram
+  HIP_TRY(hipMemsetAsync(result, 0, sizeof(ep_noalloc_result), st));
+  if (n == 0) return EP_OK;
+  const int num_tiles = (n + epk::kMpTile - 1) / epk::kMpTile;
+  HIP_TRY(hipMemsetAsync(sc, 0, kNoallocTilesOff + 8 * (size_t)num_tiles, st));
+  epk::MpScratch ms;
+  ms.ticket = (uint32_t*)sc;
+  ms.tiles = (unsigned long long*)(sc + kNoallocTilesOff);
+  ms.counts = (unsigned long long*)(sc + kNoallocCountsOff);
+  const uint32_t epoch = 1;  // the words were just cleared: no tag from an earlier call can match
+  if (P > 1 && !force_reset && np_rows > 0) {
+    HIP_TRY(hipMemsetAsync(ms.counts, 0, 8 * (size_t)N, st));
+    hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, st, players_env_id, np_rows,
+                       cfg->env_id_offset, N, ms.counts, epoch);
+    HIP_TRY(hipGetLastError());
+  }
+  epk::MpFusedArgs a;
+  a.env_id = env_id;
+  a.players_env_id = players_env_id;
+  a.list_action = force_reset ? nullptr : list_action;
+  a.sc = ms;
+  a.count_epoch = epoch;
+  a.tile_epoch = epoch;
+  a.ticket_base = 0;
+  a.env = (epk::EnvRec*)env_state;
+  a.stats = epk::StatPtrs{nullptr, nullptr, nullptr, nullptr};
+  a.slot.env_id = (int32_t*)out[0].data;
+  a.slot.penv = (int32_t*)out[1].data;
+  a.slot.elapsed = (int32_t*)out[2].data;
+  a.slot.done = (uint8_t*)out[3].data;
+  a.slot.reward = (float*)out[4].data;
+  a.slot.discount = (float*)out[5].data;
+  a.slot.step_type = (int32_t*)out[6].data;
+  a.slot.trunc = (uint8_t*)out[7].data;
+  a.slot.raw = (int32_t*)out[8].data;
+  a.slot.pdone = (uint8_t*)out[10].data;
+  a.slot.pid = (int32_t*)out[11].data;
+  a.err = (epk::ErrWords*)&result->action_check;
+  a.stamp = nullptr;
+  a.stamp_val = 0;
+  a.pc.N = N;
+  a.pc.env_off = cfg->env_id_offset;
+  a.pc.seed = cfg->seed;
+  a.pc.max_episode_steps = cfg->max_episode_steps;
+  a.pc.S = S;
+  a.slot_players = &result->num_player_rows;
+  a.host_players = nullptr;
+  a.row0 = 0;
+  a.force_reset = force_reset ? 1 : 0;
+  a.P = P;
+  a.first_segment = 1;
+  return epk_mp::launch_fused(st, a, n);
+}
+
 int32_t ep_pool_num_envs(ep_pool* p) { return p ? p->N : 0; }
 int32_t ep_pool_batch_size(ep_pool* p) { return p ? p->B : 0; }
 int32_t ep_pool_ring_depth(ep_pool* p) { return p ? p->Q : 0; }

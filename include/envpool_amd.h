@@ -199,6 +199,40 @@ int ep_batch_release(ep_batch* batch);
 int ep_pool_rollout(ep_pool* pool, int32_t T, int32_t n_arrays, const void* const* arrays,
                     const int64_t* leading_dims, const int64_t* step_stride_rows);
 
+/* One stateless send or reset that allocates nothing. No counterpart in the reference; it is for
+ * callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc. It is ep_pool_reset / ep_pool_send (async_envpool.h:57-80, 176-189) without the
+ * pool object: the caller owns the env state and the StateBuffer arrays, everything runs on
+ * `stream` and the call returns without waiting. The kernels are the pool's multi-player kernels
+ * (which also handle max_num_players == 1); their scratch (histogram counters, look-back granules,
+ * tile ticket) is a static device array inside the library, about 2.1 MB per GPU, which limits
+ * num_envs to EP_NOALLOC_MAX_ENVS. Calls no hipMalloc / hipFree or allocating routine; the first
+ * call on a device looks the array's address up (do that once outside a graph capture).
+ *   cfg         num_envs, max_num_players, seed, max_episode_steps, state_num, env_id_offset,
+ *               device_id are read; the rest is ignored
+ *   env_state   device, num_envs x {int32 state, int32 cur_step}; in/out; {0, -1} for a fresh env
+ *   n, env_id, np_rows, players_env_id, list_action   device action arrays as in ep_pool_send
+ *               (players.action / players.id are never read by the Dummy env); force_reset != 0:
+ *               only env_id is read (ep_pool_reset)
+ *   out         12 ep_array in _state_keys order with DEVICE data pointers and shape[0] = the rows
+ *               the array can take: at least n for the per-env keys, n * max_num_players for the
+ *               per-player keys (obs:dyn, index 9, is ignored); item i writes row i, player rows in
+ *               item order (one batch, like a pool with batch_size = n receives it)
+ *   result      device (or host-mapped) words, cleared by the call and written by the kernels
+ * All calls on one GPU share the scratch array: calls that overlap in time on one GPU race
+ * (serialise them on one stream). An env named twice in one call is not detected here. */
+#define EP_NOALLOC_MAX_ENVS 262144
+typedef struct {
+  uint32_t num_player_rows; /* player_offset of the batch (state_buffer.h:85-88) */
+  uint32_t action_check;    /* != 0: list_action lanes differed (EP_ERR_ACTION_CHECK of ep_pool_recv) */
+  uint32_t env_id_range;    /* != 0: an env_id outside [env_id_offset, env_id_offset + num_envs) */
+  uint32_t reserved;
+} ep_noalloc_result;
+int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n, const int32_t* env_id,
+                          int32_t np_rows, const int32_t* players_env_id, const double* list_action,
+                          int32_t force_reset, const ep_array* out, int32_t n_out, ep_noalloc_result* result,
+                          void* stream);
+
 /* Wait for everything enqueued on the pool's streams. */
 int ep_pool_sync(ep_pool* pool);
 
