@@ -45,6 +45,8 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2048)
   ap.add_argument("--warmup", type=int, default=256)
+  ap.add_argument("--repeats", type=int, default=int(os.environ.get("EP_BENCH_REPEATS", "9")),
+                  help="the timed K-step region is run this many times; the median is reported")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-ygo", action="store_true", help="skip the YGOPro observation-encode section")
   args = ap.parse_args()
@@ -130,17 +132,31 @@ def main():
         dist.all_gather_into_tensor(g_ret, st_ret)
         dist.all_gather_into_tensor(g_len, st_len)
 
+  breakdown = os.environ.get("EP_BENCH_BREAKDOWN") == "1"
+  phases = {}
+
   def run_fused(n_steps):
     # whole launches of T steps, then one shorter launch for the remainder (n_steps % T)
     chunks = [T] * (n_steps // T) + ([n_steps % T] if n_steps % T else [])
+    p0 = time.perf_counter()
     check(L.ep_pool_rollout(h, chunks[0], 5, ptrs, dims, strides))
+    p1 = time.perf_counter()
     for i in range(1, len(chunks)):
       check(L.ep_pool_rollout(h, chunks[i], 5, ptrs, dims, strides))  # next rollout queued ...
       recv_n(chunks[i - 1])                                           # ... while this one is received
       exchange_stats()
-    recv_n(chunks[-1])
-    exchange_stats()
+    # the last launch: wait for the stream first (ep_pool_sync), then receive without waiting. The
+    # region ends in a device-wide synchronisation anyway, and a stream the runtime has seen idle
+    # costs that synchronisation nothing (9 us otherwise, a quarter of a 20-step region)
     check(L.ep_pool_sync(h))
+    recv_n(chunks[-1])
+    p2 = time.perf_counter()
+    exchange_stats()
+    if world > 1:
+      check(L.ep_pool_sync(h))
+    if breakdown:
+      phases.update(first_rollout_call_us=(p1 - p0) * 1e6, until_last_recv_us=(p2 - p1) * 1e6,
+                    sync_us=(time.perf_counter() - p2) * 1e6)
 
   # reset all envs (forced reset of every env; sync-mode reset())
   check(L.ep_pool_reset(h, env_id.data_ptr(), N, capi.EP_MEM_DEVICE))
@@ -148,25 +164,42 @@ def main():
 
   if W:
     run_fused(W)
-  check(L.ep_pool_set_timing(h, 1))
+  # Clock warm-up, independent of --warmup: after idling the shader clock needs some tens of
+  # milliseconds of load to come up (the first ~150 launches after idle run 10-60 % slower), and a
+  # short timed region would otherwise measure the ramp, not the kernel. Not part of the timed steps.
+  CLOCK_WARM_LAUNCHES = int(os.environ.get("EP_BENCH_CLOCK_WARM", "192"))
+  for _ in range(CLOCK_WARM_LAUNCHES):
+    run_fused(T)
   tot = C.c_double()
   cnt = C.c_int64()
-  check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
-  barrier()
-  t0 = time.perf_counter()
-  run_fused(K)
-  barrier()
-  t1 = time.perf_counter()
-  check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
-  check(L.ep_pool_set_timing(h, 0))
-  elapsed = t1 - t0
+  R = max(1, args.repeats)
+  # The K-step region, R times; each run is bracketed by barrier + synchronize on both sides and
+  # times exactly K lockstep steps. The line reports the MEDIAN run (max over ranks per run).
+  walls, kern = [], []
+  for r in range(R):
+    check(L.ep_pool_set_timing(h, 1))
+    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    barrier()
+    t0 = time.perf_counter()
+    run_fused(K)
+    barrier()
+    t1 = time.perf_counter()
+    check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    check(L.ep_pool_set_timing(h, 0))
+    walls.append(t1 - t0)
+    kern.append((tot.value, max(1, cnt.value)))
+    if breakdown and rank == 0:
+      print(f"[breakdown] run {r}: wall {1e6 * (t1 - t0):.1f} us, kernel {tot.value:.1f} us in {cnt.value} launches, "
+            + ", ".join(f"{k} {v:.1f}" for k, v in phases.items()), file=sys.stderr, flush=True)
   if world > 1:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+    tmax = torch.tensor(walls, dtype=torch.float64, device="cpu" if rehearse else dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-  n_launch = max(1, cnt.value)
-  kern_total_us = tot.value
-  kern_us = kern_total_us / n_launch  # average rollout-kernel duration (HIP events)
+    walls = [float(x) for x in tmax.tolist()]
+  order = sorted(range(R), key=lambda i: walls[i])
+  med = order[R // 2]
+  elapsed = walls[med]
+  kern_total_us, n_launch = kern[med]
+  kern_us = kern_total_us / n_launch  # average rollout-kernel duration of the median run (HIP events)
 
   # one-launch-per-step mode, measured on rank 0's pool the same way (reported, not `value`)
   per_step = None
@@ -331,6 +364,9 @@ def main():
         ygo = {"error": repr(ex)}
 
   if rank == 0:
+    L.ep_pool_last_rollout_kernel.restype = C.c_char_p
+    L.ep_pool_last_rollout_kernel.argtypes = [C.c_void_p]
+    rollout_kernel = L.ep_pool_last_rollout_kernel(h).decode()
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
@@ -346,6 +382,8 @@ def main():
     line = {
       "metric": "env-steps/sec (whole node) Dummy-v0", "value": world * N * K / elapsed, "unit": "env-steps/s",
       "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+      "repeats": R, "clock_warm_launches": CLOCK_WARM_LAUNCHES,
+      "ms_per_step_all_runs": [w / K * 1e3 for w in walls],
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
       "data": "synthetic",
       "config": {
@@ -357,7 +395,7 @@ def main():
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "kernel": "dummy_rollout_dma<4>", "kernel_us": kern_us, "launches": n_launch,
+        "kernel": rollout_kernel, "kernel_us": kern_us, "launches": n_launch,
         "alg_bytes_per_launch": alg_launch,
       },
       "per_step_launch": per_step,

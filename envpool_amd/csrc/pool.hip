@@ -101,7 +101,12 @@ struct ep_pool {
   uint64_t alloc_count = 0, done_ptr = 0;  // StateBufferQueue::alloc_count_/done_ptr_ (in rows / batches)
   int64_t stepping_env_num = 0;            // async_envpool.h:49
   uint64_t recv_seq = 0;
-  std::deque<std::pair<uint64_t, hipEvent_t>> inflight;  // (launch id, completion event)
+  struct InFlight {
+    uint64_t first;     // launch id
+    hipEvent_t second;  // completion event
+    bool owned;         // false: the event belongs to the `timed` list (it doubles as the timing stop event)
+  };
+  std::deque<InFlight> inflight;
   std::vector<hipEvent_t> done_ev_pool;
   uint64_t launch_seq = 0;       // launches enqueued on `stream`
   uint64_t completed_launch = 0; // highest launch id known to have finished (stream is in-order)
@@ -113,6 +118,10 @@ struct ep_pool {
   int64_t recv_timeout_ms = -1;  // ep_pool_set_recv_timeout: < 0 wait like the reference, 0 never wait, > 0 bounded
   std::shared_ptr<HostBlocks> blocks;
   const char* last_rollout_kernel = "";  // which rollout kernel the last ep_pool_rollout launched
+  // work on `stream` that no launch id covers (memsets, copies, the stats snapshot) / anything on
+  // copy_stream: ep_pool_sync only has to call hipStreamSynchronize (8-10 us even on an idle stream,
+  // ROCm 7.2) when one of these is set or a launch is not yet known to have finished
+  bool stream_extra = true, copy_dirty = true;
   bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
   int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
   bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
@@ -209,6 +218,16 @@ int drain_timed(ep_pool* p) {
     p->ev_pool.push_back(ab.second);
   }
   p->timed.clear();
+  // completion entries that borrowed a timing event: those launches are finished, and their events
+  // are back in the pool now
+  for (auto it = p->inflight.begin(); it != p->inflight.end();) {
+    if (!it->owned) {
+      p->completed_launch = std::max(p->completed_launch, it->first);
+      it = p->inflight.erase(it);
+    } else {
+      ++it;
+    }
+  }
   return EP_OK;
 }
 
@@ -232,8 +251,44 @@ int mark_launch(ep_pool* p, uint64_t lid) {
   hipEvent_t e = take_done_event(p);
   if (!e) return fail(EP_ERR_HIP, "hipEventCreate failed");
   HIP_TRY(hipEventRecord(e, p->stream));
-  p->inflight.emplace_back(lid, e);
+  p->inflight.push_back({lid, e, true});
   return EP_OK;
+}
+
+void retire_front(ep_pool* p) {  // the oldest launch is known to be finished
+  if (p->inflight.front().owned) p->done_ev_pool.push_back(p->inflight.front().second);
+  p->inflight.pop_front();
+}
+
+// Events of one kernel launch. The completion event rides on the kernel's own dispatch packet
+// (hipExtLaunchKernelGGL stop event): no event packet of its own behind the kernel, about 1 us
+// less on the host and on the queue per launch. With timing on it doubles as the timing stop
+// event, and the start event is an ordinary record in front of the kernel (handing it to
+// hipExtLaunchKernelGGL as the start event costs 20 us of host time per launch on ROCm 7.2).
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool timed = false;
+};
+int begin_launch(ep_pool* p, LaunchEvents* le, hipStream_t st = nullptr) {
+  if (p->timing) {
+    le->start = get_event(p);
+    le->stop = get_event(p);
+    le->timed = true;
+    if (!le->start || !le->stop) return fail(EP_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(le->start, st ? st : p->stream));
+  } else {
+    le->stop = take_done_event(p);
+    if (!le->stop) return fail(EP_ERR_HIP, "hipEventCreate failed");
+  }
+  return EP_OK;
+}
+void abandon_launch(ep_pool* p, const LaunchEvents& le) {
+  if (le.timed) { p->ev_pool.push_back(le.start); p->ev_pool.push_back(le.stop); }
+  else p->done_ev_pool.push_back(le.stop);
+}
+void end_launch(ep_pool* p, const LaunchEvents& le, uint64_t lid) {
+  p->inflight.push_back({lid, le.stop, !le.timed});
+  if (le.timed) p->timed.emplace_back(le.start, le.stop);
 }
 
 // Blocks until launch `lid` has finished (the stream is in-order, so everything older has too).
@@ -242,19 +297,22 @@ int mark_launch(ep_pool* p, uint64_t lid) {
 // with no lock held).
 int wait_launch(ep_pool* p, uint64_t lid, std::unique_lock<std::mutex>* lk = nullptr) {
   if (lid <= p->completed_launch) return EP_OK;
-  while (!p->inflight.empty() && p->inflight.front().first < lid) {
-    p->done_ev_pool.push_back(p->inflight.front().second);  // older launch: done once `lid` is
-    p->inflight.pop_front();
-  }
+  while (!p->inflight.empty() && p->inflight.front().first < lid) retire_front(p);  // older launch: done once `lid` is
   hipEvent_t ev = nullptr;
+  bool owned = true;
   if (!p->inflight.empty() && p->inflight.front().first == lid) {
     ev = p->inflight.front().second;
+    owned = p->inflight.front().owned;
     p->inflight.pop_front();
   }
+  // (the event, not the stream: hipStreamSynchronize costs 4-5 us more per wait on ROCm 7.2. What it
+  // buys - the runtime then knows the stream is idle, so a later hipDeviceSynchronize of the caller
+  // is free instead of 9 us - is ep_pool_sync's job: callers that are about to synchronise the
+  // device call it BEFORE receiving)
   if (lk) lk->unlock();
   const hipError_t e = ev ? hipEventSynchronize(ev) : hipStreamSynchronize(p->stream);
   if (lk) lk->lock();
-  if (ev) p->done_ev_pool.push_back(ev);
+  if (ev && owned) p->done_ev_pool.push_back(ev);
   if (e != hipSuccess) return fail(EP_ERR_HIP, "waiting for launch %llu failed: %s", (unsigned long long)lid, hipGetErrorString(e));
   p->completed_launch = std::max(p->completed_launch, lid);
   return EP_OK;
@@ -264,14 +322,12 @@ int wait_launch(ep_pool* p, uint64_t lid, std::unique_lock<std::mutex>* lk = nul
 // call is known to be finished.
 int sync_stream_unlocked(ep_pool* p, std::unique_lock<std::mutex>* lk) {
   const uint64_t upto = p->launch_seq;
+  p->stream_extra = false;  // (whatever other threads enqueue during the wait sets it again)
   if (lk) lk->unlock();
   const hipError_t e = hipStreamSynchronize(p->stream);
   if (lk) lk->lock();
   if (e != hipSuccess) return fail(EP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
-  while (!p->inflight.empty() && p->inflight.front().first <= upto) {
-    p->done_ev_pool.push_back(p->inflight.front().second);
-    p->inflight.pop_front();
-  }
+  while (!p->inflight.empty() && p->inflight.front().first <= upto) retire_front(p);
   p->completed_launch = std::max(p->completed_launch, upto);
   return EP_OK;
 }
@@ -323,7 +379,7 @@ uint32_t next_stamp(ep_pool* p) {  // stamp of the launch about to be enqueued: 
 // `done_ev`, when given, rides on the kernel's own dispatch packet as its completion event (no
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-              int slot, int err_w, int row0, bool force_reset, bool check_dup, hipEvent_t done_ev = nullptr,
+              int slot, int err_w, int row0, bool force_reset, bool check_dup, const LaunchEvents& le,
               char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
   if (!st) st = p->stream;
   epk::StepArgs a;
@@ -342,13 +398,10 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
-  {
-    TimedScope ts(p);
-    if (p->S == 10)
-      hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, st, nullptr, done_ev, 0, a);
-    else
-      hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, st, nullptr, done_ev, 0, a);
-  }
+  if (p->S == 10)
+    hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, st, nullptr, le.stop, 0, a);
+  else
+    hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, st, nullptr, le.stop, 0, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
 }
@@ -400,19 +453,19 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
     // otherwise rows follow the allocation order.
     int row0 = p->is_sync ? row_base + i0 : (int)(pos % B);
-    hipEvent_t done_ev = take_done_event(p);
-    if (!done_ev) { rc = fail(EP_ERR_HIP, "hipEventCreate failed"); break; }
+    LaunchEvents le;
+    if ((rc = begin_launch(p, &le, st))) break;
     rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
                    d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0, force_reset,
-                   !host_checked && !force_reset, done_ev, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
-    if (rc != EP_OK) { p->done_ev_pool.push_back(done_ev); break; }
+                   !host_checked && !force_reset, le, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
+    if (rc != EP_OK) { abandon_launch(p, le); break; }
     SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
     sh.has_work = true;
     sh.launch_id = ++p->launch_seq;
-    p->inflight.emplace_back(sh.launch_id, done_ev);
+    end_launch(p, le, sh.launch_id);
     p->alloc_count += cnt;
     i0 += cnt;
   }
@@ -433,6 +486,7 @@ int stage_begin(ep_pool* p, int* out_idx) {
 int stage_commit(ep_pool* p, int a, size_t bytes) {
   char* h = p->h_stage + (size_t)a * p->stage_bytes;
   char* d = p->d_stage + (size_t)a * p->stage_bytes;
+  p->copy_dirty = true;
   HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, p->copy_stream));
   HIP_TRY(hipEventRecord(p->stage_copied[a], p->copy_stream));
   HIP_TRY(hipStreamWaitEvent(p->stream, p->stage_copied[a], 0));
@@ -803,6 +857,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   } else {
     // large batches: the pageable -> pinned memcpy of one piece runs while the copy engine ships
     // the piece before it (the H2D copy used to start only after the whole memcpy)
+    p->copy_dirty = true;
     HIP_TRY(hipMemcpyAsync(d, h, o2, hipMemcpyHostToDevice, p->copy_stream));
     const size_t la_bytes = 48 * (size_t)n;
     for (size_t off = 0; off < la_bytes; off += kChunk) {
@@ -874,30 +929,32 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
   // only 8-byte aligned, or a step stride that breaks the alignment, takes the generic kernel
   const bool wide_ok = ((uintptr_t)arrays[2] & 15) == 0 && ((step_stride_rows[2] * 48) & 15) == 0;
   p->last_rollout_kernel = "dummy_rollout_sp";
-  {
-    TimedScope ts(p);
-    if (p->S == 10 && p->N % epk::kWave == 0 && !p->force_generic && wide_ok) {
-      p->last_rollout_kernel = p->rollout_variant == 1 ? "dummy_rollout_wave" : p->rollout_variant == 2 ? "dummy_rollout_dma<4>" : "dummy_rollout_dma<6>";
-      // wave-autonomous software-pipelined loop (dummy_rollout_wave.hpp)
-      const dim3 g(p->N / epk::kWave), b(epk::kWave);
-      if (p->rollout_variant == 1) {
-        if (T % 4 == 0) hipLaunchKernelGGL(epk::dummy_rollout_wave<4>, g, b, 0, p->stream, a);
-        else if (T % 2 == 0) hipLaunchKernelGGL(epk::dummy_rollout_wave<2>, g, b, 0, p->stream, a);
-        else hipLaunchKernelGGL(epk::dummy_rollout_wave<1>, g, b, 0, p->stream, a);
-      } else if (p->rollout_variant == 2) {
-        hipLaunchKernelGGL(epk::dummy_rollout_dma<4>, g, b, 0, p->stream, a);
-      } else {
-        hipLaunchKernelGGL(epk::dummy_rollout_dma<6>, g, b, 0, p->stream, a);
-      }
+  LaunchEvents le;
+  if ((rc = begin_launch(p, &le))) return rc;
+  if (p->S == 10 && p->N % epk::kWave == 0 && !p->force_generic && wide_ok) {
+    p->last_rollout_kernel = p->rollout_variant == 1 ? "dummy_rollout_wave" : p->rollout_variant == 2 ? "dummy_rollout_dma<4>" : "dummy_rollout_dma<6>";
+    // wave-autonomous software-pipelined loop (dummy_rollout_wave.hpp)
+    const dim3 g(p->N / epk::kWave), b(epk::kWave);
+    if (p->rollout_variant == 1) {
+      if (T % 4 == 0) hipExtLaunchKernelGGL(epk::dummy_rollout_wave<4>, g, b, 0, p->stream, nullptr, le.stop, 0, a);
+      else if (T % 2 == 0) hipExtLaunchKernelGGL(epk::dummy_rollout_wave<2>, g, b, 0, p->stream, nullptr, le.stop, 0, a);
+      else hipExtLaunchKernelGGL(epk::dummy_rollout_wave<1>, g, b, 0, p->stream, nullptr, le.stop, 0, a);
+    } else if (p->rollout_variant == 2) {
+      hipExtLaunchKernelGGL(epk::dummy_rollout_dma<4>, g, b, 0, p->stream, nullptr, le.stop, 0, a);
     } else {
-      dim3 grid((p->N + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
-      if (p->S == 10)
-        hipLaunchKernelGGL(epk::dummy_rollout_sp<10>, grid, block, 0, p->stream, a);
-      else
-        hipLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, a);
+      hipExtLaunchKernelGGL(epk::dummy_rollout_dma<6>, g, b, 0, p->stream, nullptr, le.stop, 0, a);
     }
+  } else {
+    dim3 grid((p->N + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
+    if (p->S == 10)
+      hipExtLaunchKernelGGL(epk::dummy_rollout_sp<10>, grid, block, 0, p->stream, nullptr, le.stop, 0, a);
+    else
+      hipExtLaunchKernelGGL(epk::dummy_rollout_sp<0>, grid, block, 0, p->stream, nullptr, le.stop, 0, a);
   }
-  HIP_TRY(hipGetLastError());
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+    abandon_launch(p, le);
+    return fail(EP_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(e));
+  }
   const uint64_t lid = ++p->launch_seq;
   for (int t = 0; t < T; ++t) {
     int slot = (int)((bi0 + (uint64_t)t) % (uint64_t)p->Q);
@@ -908,7 +965,7 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
     sh.has_work = true;
     sh.launch_id = lid;
   }
-  if (int rc2 = mark_launch(p, lid)) return rc2;
+  end_launch(p, le, lid);
   p->alloc_count += (uint64_t)T * (uint64_t)p->B;
   p->stepping_env_num += (int64_t)T * p->B;
   return EP_OK;
@@ -979,6 +1036,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     int64_t cur = 0;
     bool any = false;
     auto zero_rows = [&](int64_t a, int64_t b) -> int {
+      p->stream_extra = true;
       for (int k = 0; k < 11; ++k) {
         char* base = p->d_ring + (size_t)slot * p->slot_stride + p->key_off[k];
         HIP_TRY(hipMemsetAsync(base + (size_t)a * p->key_rowbytes[k], 0, (size_t)(b - a) * p->key_rowbytes[k], p->stream));
@@ -1129,6 +1187,7 @@ int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_leng
   // destination buffers may still be read by the consumer's previous work (e.g. an all-gather)
   HIP_TRY(hipEventRecord(p->consumer_ev, cs));
   HIP_TRY(hipStreamWaitEvent(p->stream, p->consumer_ev, 0));
+  p->stream_extra = true;
   hipLaunchKernelGGL(epk::snapshot_stats, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->stats, p->N,
                      fin_return, fin_length, ep_count);
   HIP_TRY(hipGetLastError());
@@ -1155,11 +1214,17 @@ int ep_pool_sync(ep_pool* p) {
   std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
-  lk.unlock();
-  hipError_t e = hipStreamSynchronize(p->copy_stream);
-  lk.lock();
-  if (e != hipSuccess) return fail(EP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
-  if ((rc = sync_stream_unlocked(p, &lk))) return rc;
+  if (p->copy_dirty) {
+    p->copy_dirty = false;
+    lk.unlock();
+    hipError_t e = hipStreamSynchronize(p->copy_stream);
+    lk.lock();
+    if (e != hipSuccess) return fail(EP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+  }
+  // (a stream whose every launch is already known to have finished is not synchronised again:
+  // hipStreamSynchronize costs 8-10 us even then)
+  if (p->stream_extra || p->completed_launch < p->launch_seq)
+    if ((rc = sync_stream_unlocked(p, &lk))) return rc;
   // batches handed out by ep_pool_recv_on_stream: their error words are final now
   uint32_t bits = p->sticky_err;
   p->sticky_err = 0;
@@ -1351,6 +1416,7 @@ int32_t ep_pool_batch_size(ep_pool* p) { return p ? p->B : 0; }
 int32_t ep_pool_ring_depth(ep_pool* p) { return p ? p->Q : 0; }
 int32_t ep_pool_is_sync(ep_pool* p) { return p ? (p->is_sync ? 1 : 0) : 0; }
 void* ep_pool_stream(ep_pool* p) { return p ? (void*)p->stream : nullptr; }
+const char* ep_pool_last_rollout_kernel(ep_pool* p) { return p ? p->last_rollout_kernel : ""; }
 
 int ep_pool_set_timing(ep_pool* p, int32_t enabled) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");

@@ -39,7 +39,17 @@ class EnvRegistry:
         "requires environments to return an info dictionary after resets.")
     assert task_id in self.specs, f"{task_id} is not supported, `list_all_envs()` may help."
     assert env_type in ENV_TYPES
+    # build-only: one pool over several GPUs of this process (python/sharded.py). `num_envs` and
+    # `batch_size` stay the GLOBAL figures; shard r owns a contiguous block of env ids on
+    # shard_devices[r] (default: device_id + r, round robin over the visible GPUs)
+    num_shards = int(kwargs.pop("num_shards", 1))
+    shard_devices = kwargs.pop("shard_devices", None)
     spec = self.make_spec(task_id, **kwargs)
+    if num_shards > 1:
+      if task_id != "Dummy-v0":
+        raise ValueError(f"num_shards is only implemented for Dummy-v0, not {task_id}")
+      from .python.sharded import sharded_dummy_classes
+      return sharded_dummy_classes()[env_type](spec, num_shards, shard_devices)
     import_path, cls_name = self.envpools[task_id][env_type]
     return getattr(importlib.import_module(import_path), cls_name)(spec)
 

@@ -262,6 +262,9 @@ int32_t ep_pool_batch_size(ep_pool* pool);
 int32_t ep_pool_ring_depth(ep_pool* pool);
 int32_t ep_pool_is_sync(ep_pool* pool);
 void* ep_pool_stream(ep_pool* pool); /* hipStream_t the step kernels run on */
+/* Name of the kernel the last ep_pool_rollout launched ("" before the first one): which of the
+ * rollout kernels runs depends on state_num, num_envs % 64 and the alignment of list_action. */
+const char* ep_pool_last_rollout_kernel(ep_pool* pool);
 /* Average device time in microseconds of the step / rollout kernels launched
  * since the last call with reset != 0 (HIP events on the pool's stream;
  * recording is enabled by ep_pool_set_timing). */

@@ -254,3 +254,102 @@ def test_ygopro_spec_surface():
   assert s2.state_array_spec["obs:h_actions_"].shape == [8, 17]
   with pytest.raises(RuntimeError, match="duel engine"):
     envpool_amd.make("YGOPro-v0", "raw", num_envs=2)
+
+
+class _OracleShard:
+  """A shard pool for the GPU-less container: the CPU oracle behind the raw boundary."""
+
+  def __init__(self, rank, n, b, off, dev, **kw):
+    from oracle.dummy_oracle import DummyOracle
+    self.o = DummyOracle(num_envs=n, batch_size=b, env_id_offset=off, **kw)
+
+  def _send(self, a):
+    assert self.o._send(a) == 0
+
+  def _reset(self, ids):
+    assert self.o._reset(ids) == 0
+
+  def _recv(self):
+    out = self.o._recv()
+    out[9] = None
+    return out
+
+
+def _rows_by_env(batch, into):
+  for j, e in enumerate(np.asarray(batch[0]).tolist()):
+    into.setdefault(e, []).append(tuple(np.asarray(batch[k])[j].tobytes() for k in (1, 2, 3, 4, 5, 6, 7, 8, 10, 11)))
+
+
+def test_sharded_front_end_stitches_in_sent_order():
+  """the front-end splits a sent batch by owner and puts the shards' rows back in SENT
+  order (async_envpool.h:69 + state_buffer.h:92-95). Four shard pools against ONE pool of 4N envs:
+  permuted ids, partial sends, subset resets - bit-exact. (CPU oracle pools stand in for the GPU
+  pools here; tests/test_sharded_gpu.py runs the same against the product.)"""
+  from oracle.dummy_oracle import DummyOracle
+  from envpool_amd.python.sharded import ShardedRawPool
+  from tests.util import assert_batches_equal, dummy_action
+  K, n, seed, off = 4, 48, 3, 1000
+  sh = ShardedRawPool(K * n, 0, 1, 10, K, lambda *a: _OracleShard(*a, seed=seed), env_id_offset=off)
+  one = DummyOracle(num_envs=K * n, seed=seed, env_id_offset=off)
+  ids = np.arange(off, off + K * n, dtype=np.int32)
+  rng = np.random.default_rng(0)
+
+  def same(ctx):
+    got, want = sh._recv(), one._recv()
+    got[9] = want[9] = None
+    assert_batches_equal(got, want, ctx)
+
+  sh._reset(ids); one._reset(ids); same("reset")
+  for t in range(30):
+    if t % 7 == 3:      # partial send: a random subset in random order (some shards may get nothing)
+      sel = rng.permutation(ids)[: int(rng.integers(1, K * n))]
+    elif t % 7 == 5:    # everything that one shard owns, nothing else
+      sel = ids[n:2 * n][::-1].copy()
+    else:
+      sel = rng.permutation(ids)
+    pe = sel + (rng.random(sel.size) < 0.1).astype(np.int32)
+    a = dummy_action(sel, players_env_id=pe)
+    sh._send(a); one._send(a); same(f"t={t}")
+    if t == 11:
+      sub = rng.permutation(ids)[:37]
+      sh._reset(sub); one._reset(sub); same("subset reset")
+  sh._recv_empty = sh._recv()   # nothing outstanding: an empty batch, like the reference
+  assert len(sh._recv_empty[0]) == 0
+  with pytest.raises(RuntimeError, match="one send"):
+    sh._send(dummy_action(ids)); sh._send(dummy_action(ids))
+  with pytest.raises(ValueError, match="outside this pool"):
+    ShardedRawPool(8, 0, 1, 10, 2, lambda *a: _OracleShard(*a, seed=1))._send(dummy_action(np.array([8], np.int32)))
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_sharded_front_end_async_batches(P):
+  """Async mode: every shard runs with batch_size / K; a received batch is one batch of each shard
+  (BASELINE config 5's shape). Compared with one big pool per env, as sets keyed by info:env_id."""
+  from oracle.dummy_oracle import DummyOracle
+  from envpool_amd.python.sharded import ShardedRawPool
+  from tests.util import dummy_action
+  K, n, b, seed = 2, 32, 8, 2
+  sh = ShardedRawPool(K * n, K * b, P, 10, K, lambda *a: _OracleShard(*a, seed=seed, max_num_players=P))
+  one = DummyOracle(num_envs=K * n, batch_size=K * b, seed=seed, max_num_players=P)
+  ids = np.arange(K * n, dtype=np.int32)
+  sh._reset(ids); one._reset(ids)
+  got, want = {}, {}
+  for it in range(12):
+    gb, wb = [], []
+    for _ in range(n // b):
+      gb.append(sh._recv()); wb.append(one._recv())
+      assert len(gb[-1][0]) == K * b
+      _rows_by_env(gb[-1], got) if P == 1 else None
+      _rows_by_env(wb[-1], want) if P == 1 else None
+    # send every env back with one action row per player it reported
+    pe_g = np.concatenate([x[1] for x in gb]); pe_w = np.concatenate([x[1] for x in wb])
+    assert sorted(pe_g.tolist()) == sorted(pe_w.tolist())
+    for x, rows in ((gb, got), (wb, want)):
+      if P > 1:
+        for bt in x:
+          for e in np.asarray(bt[0]).tolist():
+            rows.setdefault(e, []).append(tuple(np.asarray(bt[k])[np.asarray(bt[1]) == e].tobytes() for k in (4, 5, 8, 10, 11)))
+    if P == 1:   # single player: action row i belongs to item i
+      pe_g = pe_w = ids
+    sh._send(dummy_action(ids, players_env_id=pe_g)); one._send(dummy_action(ids, players_env_id=pe_w))
+  assert got == want

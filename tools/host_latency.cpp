@@ -1,0 +1,117 @@
+// host_latency.cpp — where the host time of one lockstep step goes (GPU box, diagnostic).
+//   hipcc -O2 -std=c++17 -Iinclude tools/host_latency.cpp -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$ORIGIN/../envpool_amd' -o tools/host_latency
+// Prints per-phase host times of (a) a 20-step fused rollout bracketed by synchronisation, with
+// and without kernel timing, (b) the blocking ep_pool_send + ep_pool_recv loop, (c) ep_pool_step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "envpool_amd.h"
+
+static double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define CK(x)                                                            \
+  do {                                                                   \
+    int _rc = (x);                                                       \
+    if (_rc != 0) {                                                      \
+      fprintf(stderr, "%s -> %d: %s\n", #x, _rc, ep_last_error());       \
+      exit(1);                                                           \
+    }                                                                    \
+  } while (0)
+
+static double median(std::vector<double> v) {
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 65536, T = 20, Tbig = 128;
+  ep_dummy_config cfg{};
+  cfg.num_envs = N; cfg.max_num_players = 1; cfg.thread_affinity_offset = -1; cfg.seed = 42;
+  cfg.max_episode_steps = 2147483647; cfg.state_num = 10; cfg.action_num = 6; cfg.ring_depth = 2 * Tbig;
+  ep_pool* p = nullptr;
+  CK(ep_dummy_pool_create(&cfg, &p));
+  int32_t* d_ids; int32_t* d_penv; double* d_la;
+  hipMalloc((void**)&d_ids, 4 * (size_t)N);
+  hipMalloc((void**)&d_penv, 4 * (size_t)N * Tbig);
+  hipMalloc((void**)&d_la, 48 * (size_t)N * Tbig);
+  {
+    std::vector<int32_t> ids(N);
+    for (int i = 0; i < N; ++i) ids[i] = i;
+    hipMemcpy(d_ids, ids.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
+    for (int t = 0; t < Tbig; ++t) hipMemcpy(d_penv + (size_t)t * N, ids.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
+    std::vector<double> la((size_t)N * 6, 1.5);
+    for (int t = 0; t < Tbig; ++t) hipMemcpy(d_la + (size_t)t * N * 6, la.data(), 48 * (size_t)N, hipMemcpyHostToDevice);
+  }
+  const void* arrs[5] = {d_ids, d_penv, d_la, d_ids, d_ids};
+  int64_t dims[5] = {N, N, N, N, N}, strides[5] = {0, N, N, 0, 0};
+  std::vector<ep_batch> batches(Tbig);
+  ep_batch b;
+  CK(ep_pool_reset(p, d_ids, N, EP_MEM_DEVICE));
+  CK(ep_pool_recv(p, EP_MEM_DEVICE, &b));
+  // warm the clock
+  for (int i = 0; i < 200; ++i) {
+    CK(ep_pool_rollout(p, Tbig, 5, arrs, dims, strides));
+    CK(ep_pool_recv_many(p, EP_MEM_DEVICE, Tbig, batches.data()));
+  }
+  CK(ep_pool_sync(p));
+  for (int timing = 0; timing < 2; ++timing) {
+    CK(ep_pool_set_timing(p, timing));
+    std::vector<double> t_call, t_recv, t_sync, t_dev, t_all;
+    for (int r = 0; r < 30; ++r) {
+      hipDeviceSynchronize();
+      const double a0 = now_us();
+      CK(ep_pool_rollout(p, T, 5, arrs, dims, strides));
+      const double a1 = now_us();
+      CK(ep_pool_recv_many(p, EP_MEM_DEVICE, T, batches.data()));
+      const double a2 = now_us();
+      CK(ep_pool_sync(p));
+      const double a3 = now_us();
+      hipDeviceSynchronize();
+      const double a4 = now_us();
+      t_call.push_back(a1 - a0); t_recv.push_back(a2 - a1); t_sync.push_back(a3 - a2); t_dev.push_back(a4 - a3); t_all.push_back(a4 - a0);
+    }
+    double tot = 0; int64_t cnt = 0;
+    CK(ep_pool_kernel_time_us(p, &tot, &cnt, 1));
+    printf("rollout T=%d timing=%d: call %.1f  recv_many %.1f  pool_sync %.1f  device_sync %.1f  total %.1f us (medians of 30); kernel %.1f us\n",
+           T, timing, median(t_call), median(t_recv), median(t_sync), median(t_dev), median(t_all), cnt ? tot / cnt : 0.0);
+  }
+  CK(ep_pool_set_timing(p, 0));
+  // one launch per step, blocking
+  {
+    const void* a1[5] = {d_ids, d_ids, d_la, d_ids, d_ids};
+    std::vector<double> t_send, t_recv;
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      CK(ep_pool_send(p, 5, a1, dims, EP_MEM_DEVICE));
+      const double a1t = now_us();
+      CK(ep_pool_recv(p, EP_MEM_DEVICE, &b));
+      const double a2 = now_us();
+      if (r >= 200) { t_send.push_back(a1t - a0); t_recv.push_back(a2 - a1t); }
+    }
+    printf("send+recv per step: send %.2f  recv %.2f  total %.2f us (medians of 1800)\n", median(t_send), median(t_recv),
+           median(t_send) + median(t_recv));
+  }
+#ifdef HAVE_EP_POOL_STEP
+  {
+    const void* a1[5] = {d_ids, d_ids, d_la, d_ids, d_ids};
+    std::vector<double> t_step;
+    for (int r = 0; r < 4000; ++r) {
+      const double a0 = now_us();
+      CK(ep_pool_step(p, 5, a1, dims, &b));
+      const double a2 = now_us();
+      if (r >= 400) t_step.push_back(a2 - a0);
+    }
+    std::sort(t_step.begin(), t_step.end());
+    printf("ep_pool_step per step: median %.2f  p10 %.2f  p90 %.2f us\n", t_step[t_step.size() / 2], t_step[t_step.size() / 10],
+           t_step[t_step.size() * 9 / 10]);
+  }
+#endif
+  ep_pool_destroy(p);
+  return 0;
+}
