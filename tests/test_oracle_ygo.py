@@ -20,6 +20,16 @@ def _cfg(**kw):
   return capi_ygo.default_config(**kw)
 
 
+def _full(row, width):
+  """Golden rows are full lists or sparse {column: value} objects."""
+  if isinstance(row, dict):
+    out = [0] * width
+    for c, v in row.items():
+      out[int(c)] = v
+    return out
+  return row
+
+
 def _run_oracle(case):
   cfg = _cfg()
   table = ygo_build.make_table(GOLD["table"])
@@ -44,10 +54,10 @@ def test_known_answers(case):
   assert o["obs:global_"][0].tolist() == e["global"]
   cards = o["obs:cards_"][0]
   for r, row in e.get("cards_rows", {}).items():
-    assert cards[int(r)].tolist() == row, f"cards row {r}"
+    assert cards[int(r)].tolist() == _full(row, 39), f"cards row {r}"
   assert np.nonzero(cards.any(axis=1))[0].tolist() == e["nonzero_card_rows"]
   for r, row in e.get("actions_rows", {}).items():
-    assert o["obs:actions_"][0][int(r)].tolist() == row, f"actions row {r}"
+    assert o["obs:actions_"][0][int(r)].tolist() == _full(row, 19), f"actions row {r}"
   for r, row in e.get("h_card_ids", {}).items():
     assert o["aux:h_card_ids"][0][int(r)].tolist() == row, f"h_card_ids row {r}"
 
@@ -152,6 +162,28 @@ def test_history_push_matches_oracle_and_keeps_stale_bytes():
     assert L.ep_ygo_history_push(C.byref(cfg), ring_b.ctypes.data, C.byref(p), msg, opt.encode(), idarr.ctypes.data, len(ids)) == 0
     pb = p.value
     assert pa == pb and np.array_equal(ring_a, ring_b), (msg, opt)
+
+
+def test_history_push_known_answer():
+  """Hand-derived ring contents after three pushes into a 2-row ring (wrap + stale bytes, Q10):
+  the oracle's and the product's host ring update both have to produce them."""
+  h = GOLD["history_push"]
+  cfg = _cfg(n_history_actions=h["n_history_actions"])
+  L = capi_ygo.lib()
+  ring_o = np.zeros((h["n_history_actions"], 19), np.uint8)
+  ring_p = ring_o.copy()
+  po = pp = 0
+  for (msg, opt, ids), want_p in zip(h["script"], h["ha_p_after"]):
+    rc, po = ygo_oracle.history_push(cfg, ring_o, po, msg, opt, ids)
+    assert rc == 0 and po == want_p
+    p = C.c_int32(pp)
+    idarr = np.asarray(ids, np.uint16)
+    assert L.ep_ygo_history_push(C.byref(cfg), ring_p.ctypes.data, C.byref(p), msg, opt.encode(), idarr.ctypes.data, len(ids)) == 0
+    pp = p.value
+    assert pp == want_p
+  want = np.array([_full(h["final_ring"][str(r)], 19) for r in range(h["n_history_actions"])], np.uint8)
+  assert ring_o.tolist() == want.tolist()
+  assert ring_p.tolist() == want.tolist()
 
 
 def test_synthetic_states_are_well_formed():

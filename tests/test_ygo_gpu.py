@@ -38,8 +38,25 @@ def test_known_answers_on_gpu():
   enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
   got = enc.featurize(recs)
   _compare(got, want, np.arange(n), "known answers")
-  e = GOLD["cases"][0]["expect"]
-  assert got[8][0][1].tolist() == e["cards_rows"]["1"] and got[10][0][2].tolist() == e["actions_rows"]["2"]
+  # and the HIP path directly against the hand-derived rows (not through the oracle)
+  def full(row, width):
+    if isinstance(row, dict):
+      out = [0] * width
+      for c, v in row.items():
+        out[int(c)] = v
+      return out
+    return row
+  for i, case in enumerate(GOLD["cases"]):
+    e = case["expect"]
+    assert int(got[12][i]) == e["num_options"], case["name"]
+    assert got[9][i].tolist() == e["global"], case["name"]
+    for r, row in e.get("cards_rows", {}).items():
+      assert got[8][i][int(r)].tolist() == full(row, 39), (case["name"], "cards row", r)
+    assert np.nonzero(got[8][i].any(axis=1))[0].tolist() == e["nonzero_card_rows"], case["name"]
+    for r, row in e.get("actions_rows", {}).items():
+      assert got[10][i][int(r)].tolist() == full(row, 19), (case["name"], "actions row", r)
+    for r, row in e.get("h_card_ids", {}).items():
+      assert got[16][i][int(r)].tolist() == row, (case["name"], "h_card_ids row", r)
 
 
 @pytest.mark.parametrize("n,seed,kw", [

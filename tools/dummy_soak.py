@@ -28,6 +28,7 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
     seed = int(rng.integers(1, 2000))
     kw = dict(num_envs=n, batch_size=B, seed=seed, max_num_players=P)  # default ring depth: the reference's queue size
     g = DummyPoolC(**kw)
+    g.set_recv_timeout(0)
     o = DummyOracle(**{k: v for k, v in kw.items() if k != "ring_depth"})
     ids = np.arange(n, dtype=np.int32)
     g._reset(ids); o._reset(ids)
@@ -39,15 +40,23 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
         assert_batches_equal(got, want, f"pool {kw} it {it}")
         outstanding -= B
         last_ids = np.asarray(want[0])
-      if P > 1:  # multi-player action rows need the player layout: send the whole last batch back
-        sel = last_ids.astype(np.int32)
+      if P > 1:
+        # multi-player: one action row per player the env reported in the last batch, the envs in
+        # random order and a few of them twice (their items see the same row count, env.h:128-132)
+        sel = rng.permutation(np.unique(last_ids)).astype(np.int32)
+        if rng.random() < 0.5:
+          sel = np.concatenate([sel, rng.choice(sel, size=min(3, len(sel)))]).astype(np.int32)
+        penv = np.asarray(want[1]).astype(np.int32)
+        a = dummy_action(sel, penv)
+        g._send(a); o._send(a)
+        outstanding += len(sel)
+        steps_total += len(sel)
+        continue
       elif sync:
         sel = ids if rng.random() < 0.8 else rng.permutation(n).astype(np.int32)
       else:
         # with repeats: an env named twice in one send is stepped twice, in order
         sel = rng.choice(last_ids, size=int(rng.integers(1, len(last_ids) + 1)), replace=True).astype(np.int32)
-      if P > 1:
-        break  # (multi-player sends are covered by the test-suite; here only reset + first batches)
       penv = sel + (rng.random(len(sel)) < 0.1).astype(np.int32)
       a = dummy_action(sel, penv)
       g._send(a); o._send(a)
