@@ -39,7 +39,7 @@ oracle:
 synth: tools/libygosynth.so
 
 tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpool_amd.h
-	gcc -O2 -fPIC -shared -std=c11 -Wall -o $@ $<
+	gcc -O2 -fPIC -shared -std=gnu11 -Wall -pthread -o $@ $<
 
 clean:
 	rm -f $(LIB) $(PYMODS) tools/libygosynth.so

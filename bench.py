@@ -331,6 +331,7 @@ def main():
         "config3_kernel_us": c3["kernel_us"], "config3_zero_copy": c3.get("zero_copy"),
         "config3_staging_copy_us": c3["h2d_copy_us"],
         "host_emit_records_per_s_1core": r["host_emit_records_per_s_1core"],
+        "config5_async_ring": r.get("config5_async_ring"),
       }
       if "cpu_oracle_encodes_per_s_1core" in r:
         ygo["cpu_baseline"] = {"value": r["cpu_oracle_encodes_per_s_1core"], "unit": "encodes/s", "cores": 1, "kind": "port",
@@ -350,11 +351,17 @@ def main():
       r = bench_ygo.run_shard(dev_index, barrier)
       tm = torch.tensor([r["large_wall_s"], r["pipeline_wall_s"]], dtype=torch.float64, device="cpu" if rehearse else dev)
       dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+      ring = torch.tensor([r["ring_4_threads"]["batches_per_s"], r["ring_4_threads"]["gpu_time_hidden_behind_emission"] or 0.0],
+                          dtype=torch.float64, device="cpu" if rehearse else dev)
+      dist.all_reduce(ring, op=dist.ReduceOp.SUM)
       if rank == 0:
         ygo = {
           "metric": "ygopro obs-encodes/s", "unit": "encodes/s", "scaling": "weak",
           "value_device_resident": world * r["large_records"] / float(tm[0].item()),
           "value_config5_host_records_pcie_inclusive": world * r["pipeline_records"] / float(tm[1].item()),
+          "config5_async_ring": {"producer_threads_per_gpu": 4, "batches_per_s_all_gpus": float(ring[0].item()),
+                                 "gpu_time_hidden_behind_emission_mean": float(ring[1].item()) / world,
+                                 "rank0": r["ring_4_threads"]},
           "config": {"workload": f"YGOPro-v0 observation-encode tail, default config, synthetic duel states, {world} ranks: "
                                  f"{r['records_per_launch']} device-resident records per launch per GPU, and BASELINE config 5's "
                                  f"per-GPU shape, {r['records_per_step']} host records per step written in place into the pinned slots"},

@@ -5,10 +5,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -81,12 +84,23 @@ struct ep_ygo_encoder {
   uint64_t submit_idx = 0, collect_idx = 0;
   int lds_bytes = 0;
   std::mutex mu;
+  std::recursive_mutex featurize_mu;  // ep_ygo_featurize = submit + collect, atomically with respect to the other submitters
   std::shared_ptr<epc::HostBlocks> blocks;
   bool timing = false;
   bool zero_copy = true;  // the kernel reads the pinned slot over PCIe itself (no staging copy); EP_YGO_ZERO_COPY=0: stage through d_rec
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
   double timed_total_us = 0;
   int64_t timed_launches = 0;
+  // arrival-ordered record ring (ep_ygo_async_begin / alloc_record / record_done / recv): the
+  // counters of StateBufferQueue / StateBuffer (state_buffer_queue.h:114-150, state_buffer.h:79-129)
+  int async_B = 0;                             // batch_size of this mode; 0 = submit/collect mode
+  std::atomic<uint64_t> a_alloc{0};            // records handed out (StateBufferQueue::alloc_count_)
+  std::atomic<uint64_t> a_recv{0};             // batches received   (StateBufferQueue::done_ptr_)
+  std::unique_ptr<std::atomic<int>[]> a_done;  // [ring] records finished in the slot (StateBuffer::done_count_)
+  std::vector<uint64_t> a_committed;           // [ring] 1 + index of the batch whose kernel is enqueued in the slot, 0 = none
+  std::condition_variable cv_space, cv_ready;
+  int64_t a_recv_timeout_ms = -1;
+  std::atomic<uint64_t> a_space_wait_ns{0};    // time producers spent waiting for a free slot (ring full)
 };
 
 namespace {
@@ -386,6 +400,7 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
 int ep_ygo_acquire_slot(ep_ygo_encoder* e, void** pinned_records) {
   if (!e || !pinned_records) return fail(EP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->async_B) return fail(EP_ERR_INVALID, "the encoder is in arrival-ordered mode (ep_ygo_async_begin)");
   if (e->submit_idx - e->collect_idx >= e->slots.size())
     return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
   *pinned_records = e->slots[e->submit_idx % e->slots.size()].h_rec;
@@ -394,7 +409,9 @@ int ep_ygo_acquire_slot(ep_ygo_encoder* e, void** pinned_records) {
 
 int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {
   if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::recursive_mutex> whole(e->featurize_mu);
   std::lock_guard<std::mutex> lk(e->mu);
+  if (e->async_B) return fail(EP_ERR_INVALID, "the encoder is in arrival-ordered mode (ep_ygo_async_begin)");
   if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
   if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
   if (e->submit_idx - e->collect_idx >= e->slots.size())
@@ -433,6 +450,7 @@ int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {
 
 int ep_ygo_submit(ep_ygo_encoder* e, const void* host_records, int32_t n) {
   if (!e || (!host_records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> whole(e->featurize_mu);  // acquire + copy + commit: one slot, one owner
   if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
   void* dst = nullptr;
   int rc = ep_ygo_acquire_slot(e, &dst);
@@ -465,6 +483,18 @@ int ep_ygo_collect(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
 int ep_ygo_featurize(ep_ygo_encoder* e, const void* records, int32_t n, int32_t mem_in, int32_t mem_out, ep_batch* out) {
   if (!e || !out || (!records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
   if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
+  // submit + collect as ONE operation: collect hands out the OLDEST batch in flight, so with
+  // another batch still in flight (or another thread submitting in between) the caller would get
+  // somebody else's results for its records
+  std::lock_guard<std::recursive_mutex> whole(e->featurize_mu);
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->async_B) return fail(EP_ERR_INVALID, "the encoder is in arrival-ordered mode (ep_ygo_async_begin)");
+    if (e->submit_idx != e->collect_idx)
+      return fail(EP_ERR_INVALID, "%llu batches are in flight from ep_ygo_submit / ep_ygo_commit_slot: collect them first "
+                                  "(ep_ygo_featurize returns the batch it was given, ep_ygo_collect the oldest one)",
+                  (unsigned long long)(e->submit_idx - e->collect_idx));
+  }
   if (mem_in == EP_MEM_HOST) {
     int rc = ep_ygo_submit(e, records, n);
     if (rc) return rc;
@@ -477,6 +507,7 @@ int ep_ygo_featurize(ep_ygo_encoder* e, const void* records, int32_t n, int32_t 
 
 int ep_ygo_submit_device(ep_ygo_encoder* e, const void* device_records, int32_t n) {
   if (!e || (!device_records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> whole(e->featurize_mu);
   if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
   // device-resident records: no staging, the kernel reads the caller's buffer
   std::lock_guard<std::mutex> lk(e->mu);
@@ -494,6 +525,141 @@ int ep_ygo_submit_device(ep_ygo_encoder* e, const void* device_records, int32_t 
   HIP_TRY(hipEventRecord(s.done, e->stream));
   s.busy = true;
   e->submit_idx++;
+  return EP_OK;
+}
+
+// ---- arrival-ordered record ring ----------------------------------------------------------
+// BASELINE config 5: duel threads finish their env-steps in no particular order; each takes the
+// next row of the batch being filled (one atomic add: StateBufferQueue::Allocate,
+// state_buffer_queue.h:114-128), writes its record IN PLACE into the pinned slot, and reports it
+// done (StateBuffer::Done, state_buffer.h:124-129); the thread whose record completes the batch
+// enqueues the encode kernel. Batches are handed out in order by ep_ygo_recv
+// (StateBufferQueue::Wait, :139-150). Nothing is copied on the host.
+int ep_ygo_async_begin(ep_ygo_encoder* e, int32_t batch_size) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (batch_size < 1 || batch_size > e->cfg.max_batch)
+    return fail(EP_ERR_INVALID, "batch_size = %d outside [1, max_batch = %d]", batch_size, e->cfg.max_batch);
+  if (e->submit_idx != e->collect_idx) return fail(EP_ERR_INVALID, "batches in flight: collect them first");
+  if (e->async_B && e->a_alloc.load() != e->a_recv.load() * (uint64_t)e->async_B)
+    return fail(EP_ERR_INVALID, "records of the previous arrival-ordered run are still outstanding");
+  if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
+  if (e->slots.size() < 2) return fail(EP_ERR_INVALID, "arrival-ordered mode needs ring_depth >= 2");
+  e->async_B = batch_size;
+  e->a_alloc.store(0);
+  e->a_recv.store(0);
+  e->a_space_wait_ns.store(0);
+  e->a_done.reset(new std::atomic<int>[e->slots.size()]);
+  for (size_t i = 0; i < e->slots.size(); ++i) e->a_done[i].store(0);
+  e->a_committed.assign(e->slots.size(), 0);
+  return EP_OK;
+}
+
+int ep_ygo_alloc_record(ep_ygo_encoder* e, void** record, uint64_t* ticket) {
+  if (!e || !record || !ticket) return fail(EP_ERR_INVALID, "null argument");
+  const int B = e->async_B;
+  if (!B) return fail(EP_ERR_INVALID, "call ep_ygo_async_begin first");
+  const uint64_t depth = e->slots.size();
+  const uint64_t pos = e->a_alloc.fetch_add(1, std::memory_order_relaxed);
+  const uint64_t bi = pos / (uint64_t)B;
+  // the slot of batch bi held batch bi - depth, and the views of the batch received last are still
+  // the consumer's: the slot is free once batch bi - depth + 1 has been received as well. (The
+  // reference throws out_of_range when its queue overflows, state_buffer.h:111; producers wait here.)
+  if (bi + 1 >= e->a_recv.load(std::memory_order_acquire) + depth) {
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+      std::unique_lock<std::mutex> lk(e->mu);
+      e->cv_space.wait(lk, [&] { return bi + 1 < e->a_recv.load(std::memory_order_acquire) + depth; });
+    }
+    e->a_space_wait_ns.fetch_add(
+        (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+        std::memory_order_relaxed);
+  }
+  *record = e->slots[bi % depth].h_rec + (pos % (uint64_t)B) * (uint64_t)e->lay.stride;
+  *ticket = pos;
+  return EP_OK;
+}
+
+int ep_ygo_record_done(ep_ygo_encoder* e, uint64_t ticket) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  const int B = e->async_B;
+  if (!B) return fail(EP_ERR_INVALID, "call ep_ygo_async_begin first");
+  const uint64_t depth = e->slots.size();
+  const uint64_t bi = ticket / (uint64_t)B;
+  const int si = (int)(bi % depth);
+  // acq_rel: the thread that sees the B-th completion also sees every record of the batch
+  if (e->a_done[si].fetch_add(1, std::memory_order_acq_rel) + 1 != B) return EP_OK;
+  e->a_done[si].store(0, std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  Slot& s = e->slots[si];
+  s.n = B;
+  hipStream_t st = (bi & 1) ? e->copy_stream : e->stream;
+  int rc;
+  if (e->zero_copy) {
+    void* dev_view = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev_view, s.h_rec, 0));
+    rc = launch(e, (const char*)dev_view, B, si, /*lean_fetch=*/true, st);
+  } else {
+    st = e->stream;
+    HIP_TRY(hipMemcpyAsync(s.d_rec, s.h_rec, (size_t)B * e->lay.stride, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+    rc = launch(e, s.d_rec, B, si);
+  }
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(s.done, st));
+  e->a_committed[si] = bi + 1;
+  e->cv_ready.notify_all();
+  return EP_OK;
+}
+
+int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
+  if (!e || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (!e->async_B) return fail(EP_ERR_INVALID, "call ep_ygo_async_begin first");
+  std::unique_lock<std::mutex> lk(e->mu);
+  const uint64_t depth = e->slots.size();
+  const uint64_t bi = e->a_recv.load(std::memory_order_relaxed);
+  const int si = (int)(bi % depth);
+  auto ready = [&] { return e->a_committed[si] == bi + 1; };
+  if (!ready()) {
+    if (e->a_recv_timeout_ms == 0) return fail(EP_ERR_WOULD_BLOCK, "batch %llu is not complete yet", (unsigned long long)bi);
+    if (e->a_recv_timeout_ms < 0) e->cv_ready.wait(lk, ready);
+    else if (!e->cv_ready.wait_for(lk, std::chrono::milliseconds(e->a_recv_timeout_ms), ready))
+      return fail(EP_ERR_WOULD_BLOCK, "batch %llu is not complete yet", (unsigned long long)bi);
+  }
+  lk.unlock();
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipEventSynchronize(e->slots[si].done));
+  lk.lock();
+  e->collect_idx = bi;  // (describe() numbers the batch with it)
+  int rc = describe(e, si, mem_out, out);
+  e->collect_idx = e->submit_idx = 0;
+  if (rc) return rc;
+  e->a_committed[si] = 0;
+  const bool bad = e->h_err[si] != 0;
+  e->h_err[si] = 0;
+  e->a_recv.store(bi + 1, std::memory_order_release);
+  e->cv_space.notify_all();
+  if (bad)
+    return fail(EP_ERR_ACTION_CHECK,
+                "a record hit a condition on which the reference throws (unknown card code / attribute / race / "
+                "position / phase, a spec that is not on the field, or more rows than max_cards)");
+  return EP_OK;
+}
+
+int ep_ygo_ring_stats(ep_ygo_encoder* e, double* producer_wait_seconds, uint64_t* records, uint64_t* batches_received) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  if (producer_wait_seconds) *producer_wait_seconds = 1e-9 * (double)e->a_space_wait_ns.load();
+  if (records) *records = e->a_alloc.load();
+  if (batches_received) *batches_received = e->a_recv.load();
+  return EP_OK;
+}
+
+int ep_ygo_set_recv_timeout(ep_ygo_encoder* e, int64_t milliseconds) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->a_recv_timeout_ms = milliseconds;
   return EP_OK;
 }
 

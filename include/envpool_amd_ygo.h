@@ -143,7 +143,9 @@ int32_t ep_ygo_action_feats(const ep_ygo_config* cfg);
  * info:num_options, info:to_play, info:is_selfplay, info:win_reason) followed by one
  * additive key: aux:h_card_ids uint16 [n, max_options, max_multi_select] (the
  * back-derivation of :1863-1879, so the host ring update needs no GPU read-back of obs).
- * Blocking. Returns EP_ERR_ACTION_CHECK when a record tripped a condition on which the
+ * Blocking. Submit and collect as ONE operation: refused with EP_ERR_INVALID while batches of
+ * ep_ygo_submit / ep_ygo_commit_slot are in flight (it returns the batch it was given, not the
+ * oldest one). Returns EP_ERR_ACTION_CHECK when a record tripped a condition on which the
  * reference throws (unknown card code / attribute / race / position / phase / message,
  * spec not on the field, more rows than max_cards); the batch is still returned. */
 int ep_ygo_featurize(ep_ygo_encoder* enc, const void* records, int32_t n, int32_t mem_in,
@@ -165,6 +167,35 @@ int ep_ygo_submit_device(ep_ygo_encoder* enc, const void* device_records, int32_
  * place (no memcpy): acquire -> fill n records -> commit. */
 int ep_ygo_acquire_slot(ep_ygo_encoder* enc, void** pinned_records);
 int ep_ygo_commit_slot(ep_ygo_encoder* enc, int32_t n);
+/* Arrival-ordered record ring: BASELINE config 5 (async mode, batch_size < num_envs). Duel threads
+ * finish env-steps in no particular order; each takes the next row of the batch being filled,
+ * emits its record IN PLACE into the pinned slot and reports it done; the batch is encoded as soon
+ * as its batch_size-th record has landed, and batches are received in order. The counterparts:
+ *   ep_ygo_async_begin   puts the encoder into this mode (no batch may be in flight); batch_size
+ *                        <= max_batch; up to ring_depth - 1 batches can be filled ahead of the
+ *                        consumer
+ *   ep_ygo_alloc_record  StateBufferQueue::Allocate + StateBuffer::Allocate
+ *                        (state_buffer_queue.h:114-128, state_buffer.h:79-112): one atomic add
+ *                        hands out (batch, row) in ARRIVAL order; *record points at that row of the
+ *                        pinned slot (ep_ygo_record_stride bytes, to be filled by
+ *                        ep_ygo_emit_record), *ticket names it. Any number of threads. Waits while
+ *                        the ring is full (the reference throws out_of_range there, state_buffer.h:111)
+ *   ep_ygo_record_done   StateBuffer::Done (state_buffer.h:124-129): the call that completes a
+ *                        batch enqueues its encode kernel (zero-copy or staged, ep_ygo_set_zero_copy)
+ *   ep_ygo_recv          StateBufferQueue::Wait (state_buffer_queue.h:139-150): blocks until the
+ *                        next batch in order is complete and encoded (ep_ygo_set_recv_timeout as for
+ *                        pools), then describes it like ep_ygo_collect; single consumer. Device views
+ *                        stay valid until the next ep_ygo_recv. Rows are in arrival order: compare
+ *                        with the reference as sets keyed by info:env_id. */
+int ep_ygo_async_begin(ep_ygo_encoder* enc, int32_t batch_size);
+int ep_ygo_alloc_record(ep_ygo_encoder* enc, void** record, uint64_t* ticket);
+int ep_ygo_record_done(ep_ygo_encoder* enc, uint64_t ticket);
+int ep_ygo_recv(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);
+int ep_ygo_set_recv_timeout(ep_ygo_encoder* enc, int64_t milliseconds);
+/* Counters of the arrival-ordered ring since ep_ygo_async_begin: the time producer threads spent
+ * waiting for a free slot (the only place where the GPU side can hold the duel threads up), the
+ * records handed out and the batches received. Any pointer may be NULL. */
+int ep_ygo_ring_stats(ep_ygo_encoder* enc, double* producer_wait_seconds, uint64_t* records, uint64_t* batches_received);
 /* How a committed slot reaches the kernel. enabled != 0 (the default; EP_YGO_ZERO_COPY=0 in the
  * environment changes the default): the kernel reads the USED part of every record straight from
  * the pinned slot over PCIe - no staging copy, about half the PCIe bytes of a fixed-stride copy;

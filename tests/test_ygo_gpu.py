@@ -304,3 +304,90 @@ def test_full_size_batch_properties():
     acc = part if acc is None else [x + y for x, y in zip(acc, part)]
   small.close()
   assert acc == checksum(got)
+
+
+@pytest.mark.parametrize("threads,zero_copy", [(1, 1), (4, 1), (7, 0)])
+def test_arrival_ordered_ring_with_producer_threads(threads, zero_copy):
+  """BASELINE config 5's shape on one GPU (1024 envs, 512-record batches): host producer threads
+  emit records in place into rows handed out in ARRIVAL order (the YGO analogue of
+  state_buffer_queue.h:114-128 + state_buffer.h:79-129), the batch is encoded when its 512th record
+  lands, the consumer receives batches in order. Rows arrive in any order, so the comparison with
+  the oracle is by (info:env_id, elapsed_step) - bit-exact on every key."""
+  import ctypes as C
+  import threading
+
+  from envpool_amd import capi
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  N, B, steps = 1024, 512, 3
+  cfg = capi_ygo.default_config(max_batch=B, ring_depth=3)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, N, seed=11)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  L = capi_ygo.lib()
+  capi._check(L.ep_ygo_set_zero_copy(enc.handle, zero_copy))
+  capi._check(L.ep_ygo_async_begin(enc.handle, B))
+  capi._check(L.ep_ygo_set_recv_timeout(enc.handle, 30000))
+  res = {}
+  prod = threading.Thread(target=lambda: res.update(rc=ygo_synth.run_producers(enc.handle, cfg, sb.raw, N, threads, steps, engine_us=2.0)))
+  prod.start()
+  got = {}
+  for bi in range(N * steps // B):
+    b = capi.Batch()
+    rc = L.ep_ygo_recv(enc.handle, capi.EP_MEM_HOST, C.byref(b))
+    assert rc in (0, capi.EP_ERR_ACTION_CHECK), L.ep_last_error()
+    assert b.num_rows == B and b.seq == bi
+    out = capi.batch_to_numpy(b)
+    L.ep_batch_release(C.byref(b))
+    for j in range(B):
+      key = (int(out[0][j]), int(out[2][j]))
+      assert key not in got, f"row {key} handed out twice"
+      got[key] = tuple(np.asarray(out[k][j]).tobytes() for k in range(len(K)))
+  prod.join(timeout=60)
+  assert not prod.is_alive() and res["rc"][0] == 0
+  # nothing more is pending
+  capi._check(L.ep_ygo_set_recv_timeout(enc.handle, 0))
+  b = capi.Batch()
+  assert L.ep_ygo_recv(enc.handle, capi.EP_MEM_HOST, C.byref(b)) == capi.EP_ERR_WOULD_BLOCK
+  # the oracle on the same states, step by step
+  raw = (capi_ygo.RawState * N)()
+  n_checked = 0
+  for s in range(steps):
+    for i in range(N):
+      C.memmove(C.byref(raw[i]), C.byref(sb.raw[i]), C.sizeof(capi_ygo.RawState))
+      raw[i].elapsed_step = s
+    want, status = ygo_oracle.write_batch(cfg, table, raw, N)
+    for i in range(N):
+      if status[i] != 0:
+        continue  # the reference throws on this state; the product flags the batch
+      key = (int(want[0][i]), s)
+      assert got[key] == tuple(np.asarray(want[k][i]).tobytes() for k in range(len(K))), key
+      n_checked += 1
+  assert len(got) == N * steps and n_checked > 0.9 * N * steps
+  # submit/collect is refused in this mode, and featurize refuses to run beside in-flight batches
+  assert L.ep_ygo_commit_slot(enc.handle, 1) == capi.EP_ERR_INVALID
+  enc.close()
+
+
+def test_featurize_returns_its_own_batch():
+  """ep_ygo_featurize is submit + collect as one operation: with a batch of ep_ygo_submit still in
+  flight it must not hand out that older batch for the records it was given."""
+  import ctypes as C
+
+  from envpool_amd import capi
+  from tools import ygo_synth
+  cfg = capi_ygo.default_config(max_batch=64)
+  table = ygo_synth.make_table(1000, seed=0)
+  sa = ygo_synth.SynthBatch(cfg, table, 8, seed=1)
+  sb = ygo_synth.SynthBatch(cfg, table, 8, seed=2, first=100)
+  ra, _ = capi_ygo.emit_records(cfg, sa.raw, 8)
+  rb, _ = capi_ygo.emit_records(cfg, sb.raw, 8)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  enc.submit(ra)
+  with pytest.raises(capi.EpError) as e:
+    enc.featurize(rb)
+  assert e.value.code == capi.EP_ERR_INVALID and "in flight" in str(e.value)
+  a = enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,))
+  b = enc.featurize(rb, allow=(capi.EP_ERR_ACTION_CHECK,))
+  assert a[0].tolist() == [int(sa.raw[i].env_id) for i in range(8)]
+  assert b[0].tolist() == [int(sb.raw[i].env_id) for i in range(8)]

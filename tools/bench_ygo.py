@@ -160,6 +160,10 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
 
   res = {"large_batch": big_res, "config3_host_pipeline": cfg3_res, "config5_per_gpu_host_pipeline": cfg5_res,
          "host_emit_records_per_s_1core": n_gen / emit_s}
+  try:
+    res["config5_async_ring"] = run_config5(device)
+  except Exception as ex:  # noqa: BLE001
+    res["config5_async_ring"] = {"error": repr(ex)}
   if cpu_seconds > 0:
     from oracle import ygo_oracle
     n_cpu = 2048
@@ -171,6 +175,75 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
     res["cpu_oracle_encodes_per_s_1core"] = done / (time.perf_counter() - c0)
   return res
 
+
+def run_config5(device=0, threads_list=(1, 4, 12, 16), n_envs=1024, batch=512, steps_per_env=40, engine_us=None):
+  """BASELINE config 5 per GPU: async mode, 1024 envs, 512-record batches. Host producer threads (a
+  stand-in duel engine spending `engine_us` per env-step, tools/ygo_synth.c) emit records in place
+  into the encoder's arrival-ordered pinned ring; the batch is encoded (zero-copy PCIe reads) when
+  its 512th record lands; one consumer receives the batches as device views. Per thread count:
+  batches/s, and how much of the GPU side (kernel incl. its PCIe reads) is hidden behind emission.
+  The duel threads are the critical path; the GPU side is exposed only where it holds them up (the
+  time they wait for a free ring slot) and in the tail after the last record (its batch's kernel):
+  hidden = 1 - (producer wait + tail) / GPU time. The producers-alone run (records into a private
+  scratch record) gives the cost of the ring itself per record."""
+  import threading
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  if engine_us is None:
+    engine_us = float(os.environ.get("EP_YGO_ENGINE_US", "20"))
+  L = capi_ygo.lib()
+  cfg = capi_ygo.default_config(max_batch=batch, ring_depth=4, device_id=device)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, n_envs, seed=5)
+  n_batches = n_envs * steps_per_env // batch
+  tot, cnt = C.c_double(), C.c_int64()
+  b = capi.Batch()
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  out = {"envs": n_envs, "batch_size": batch, "engine_us_per_env_step": engine_us, "records": n_envs * steps_per_env,
+         "note": "the box gives one GPU's job 16 host cores: 16 producer threads plus the consumer oversubscribe them",
+         "by_threads": {}}
+  for nt in threads_list:
+    enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+    h = enc.handle
+    assert L.ep_ygo_async_begin(h, batch) == 0
+    # producers alone (records into a private scratch record, no ring, no GPU)
+    s0 = time.perf_counter()
+    rc, _ = ygo_synth.run_producers(h, cfg, sb.raw, n_envs, nt, steps_per_env, engine_us, sink_only=True)
+    sink_s = time.perf_counter() - s0
+    assert rc == 0
+    L.ep_ygo_set_timing(h, 1)
+    L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+    res = {}
+
+    def produce():
+      r = ygo_synth.run_producers(h, cfg, sb.raw, n_envs, nt, steps_per_env, engine_us)
+      res.update(r=r, done_at=time.perf_counter())
+    th = threading.Thread(target=produce)
+    w0 = time.perf_counter()
+    th.start()
+    for _ in range(n_batches):
+      assert L.ep_ygo_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    last_recv = time.perf_counter()
+    th.join()
+    wall = last_recv - w0
+    assert res["r"][0] == 0
+    L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+    gpu_s = tot.value * 1e-6
+    wait_s = C.c_double()
+    L.ep_ygo_ring_stats(h, C.byref(wait_s), None, None)
+    tail_s = max(0.0, last_recv - res["done_at"])
+    hidden = max(0.0, min(1.0, 1.0 - (wait_s.value + tail_s) / gpu_s)) if gpu_s > 0 else None
+    recs_n = n_envs * steps_per_env
+    out["by_threads"][str(nt)] = {
+      "batches_per_s": n_batches / wall, "encodes_per_s_pcie_inclusive": recs_n / wall,
+      "wall_s": wall, "producers_alone_s": sink_s, "ring_overhead_us_per_record": (wall - sink_s) / recs_n * 1e6,
+      "gpu_kernel_s": gpu_s, "kernel_us_per_batch": tot.value / max(1, cnt.value),
+      "emit_us_per_record": res["r"][1] / recs_n * 1e6, "producer_wait_for_slot_s": wait_s.value, "tail_s": tail_s,
+      "gpu_time_hidden_behind_emission": hidden}
+    enc.close()
+  return out
 
 
 def run_shard(device, barrier, n_big=65536, n_step=512, iters=200, steps=400):
@@ -236,8 +309,10 @@ def run_shard(device, barrier, n_big=65536, n_step=512, iters=200, steps=400):
   barrier()
   t_step = time.perf_counter() - t0
   encp.close()
+  # config 5 as a whole on this rank: 4 stand-in duel threads feeding the arrival-ordered ring
+  ring = run_config5(device, threads_list=(4,), steps_per_env=20)["by_threads"]["4"]
   return {"large_wall_s": t_big, "large_records": n_big * iters, "pipeline_wall_s": t_step, "pipeline_records": n_step * steps,
-          "records_per_launch": n_big, "records_per_step": n_step}
+          "records_per_launch": n_big, "records_per_step": n_step, "ring_4_threads": ring}
 
 if __name__ == "__main__":
   print(json.dumps(run(cpu_seconds=float(os.environ.get("EP_YGO_CPU_SECONDS", "3")))))

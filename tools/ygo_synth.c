@@ -336,3 +336,92 @@ void ys_free_batch(ys_state** h, int32_t n) {
   for (int i = 0; i < n; ++i) ys_free(h[i]);
   free(h);
 }
+
+/* ---- stand-in duel engine for BASELINE config 5 ------------------------------------------------
+ * `n_threads` producer threads; thread t owns the envs t, t + n_threads, ... of `states`. Per
+ * env-step a thread spends `engine_us` microseconds "in the engine" (a busy wait: the Lua duel
+ * engine is not part of this library), then takes the next row of the encoder's arrival-ordered
+ * ring, emits the env's record IN PLACE and reports it done. The record carries the step index in
+ * elapsed_step, so a test can key every received row by (env_id, elapsed_step). sink_only != 0:
+ * records go to a thread-private scratch record instead of the ring (the cost of emission alone).
+ * The ring's entry points come in as function pointers: this file does not link the product. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+  int (*alloc_record)(void* enc, void** record, uint64_t* ticket);
+  int (*emit_record)(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
+  int (*record_done)(void* enc, uint64_t ticket);
+  int64_t (*record_stride)(const ep_ygo_config* cfg);
+} ys_ring_api;
+
+typedef struct {
+  void* enc;
+  const ys_ring_api* api;
+  const ep_ygo_config* cfg;
+  const ygo_raw_state* states;
+  int32_t n_envs, n_threads, tid, steps_per_env, sink_only;
+  double engine_us;
+  int rc;
+  double emit_seconds; /* time inside alloc + emit + done */
+} ys_prod_arg;
+
+static double ys_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* ys_producer(void* v) {
+  ys_prod_arg* a = (ys_prod_arg*)v;
+  void* scratch = NULL;
+  if (a->sink_only) scratch = malloc((size_t)a->api->record_stride(a->cfg));
+  for (int s = 0; s < a->steps_per_env && a->rc == 0; ++s) {
+    for (int e = a->tid; e < a->n_envs && a->rc == 0; e += a->n_threads) {
+      if (a->engine_us > 0) {
+        const double until = ys_now() + 1e-6 * a->engine_us;
+        while (ys_now() < until) {}
+      }
+      ygo_raw_state st = a->states[e]; /* shallow copy: the buffers it points into are read-only */
+      st.elapsed_step = s;
+      const double t0 = ys_now();
+      void* rec = scratch;
+      uint64_t ticket = 0;
+      if (!a->sink_only && (a->rc = a->api->alloc_record(a->enc, &rec, &ticket)) != 0) break;
+      int erc = a->api->emit_record(a->cfg, &st, rec);
+      if (erc != 0) {
+        /* a state the emitter refuses still has to fill its row: an empty record (no options) */
+        ygo_raw_state empty = st;
+        empty.n_options = 0;
+        a->api->emit_record(a->cfg, &empty, rec);
+      }
+      if (!a->sink_only) a->rc = a->api->record_done(a->enc, ticket);
+      a->emit_seconds += ys_now() - t0;
+    }
+  }
+  free(scratch);
+  return NULL;
+}
+
+int ys_run_producers(void* enc, const ys_ring_api* api, const ep_ygo_config* cfg, const ygo_raw_state* states,
+                     int32_t n_envs, int32_t n_threads, int32_t steps_per_env, double engine_us, int32_t sink_only,
+                     double* emit_seconds_out) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
+  pthread_t th[64];
+  ys_prod_arg arg[64];
+  int started = 0, rc = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    arg[t] = (ys_prod_arg){enc, api, cfg, states, n_envs, n_threads, t, steps_per_env, sink_only, engine_us, 0, 0.0};
+    if (pthread_create(&th[t], NULL, ys_producer, &arg[t]) != 0) { rc = -1; break; }
+    ++started;
+  }
+  double emit = 0;
+  for (int t = 0; t < started; ++t) {
+    pthread_join(th[t], NULL);
+    if (arg[t].rc && !rc) rc = arg[t].rc;
+    emit += arg[t].emit_seconds;
+  }
+  if (emit_seconds_out) *emit_seconds_out = emit;
+  return rc;
+}

@@ -21,8 +21,34 @@ def lib():
     L.ys_gen_batch.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.POINTER(YgoConfig), C.POINTER(CardData), C.c_int32,
                                C.POINTER(RawState)]
     L.ys_free_batch.argtypes = [C.c_void_p, C.c_int32]
+    L.ys_run_producers.argtypes = [C.c_void_p, C.POINTER(RingApi), C.POINTER(YgoConfig), C.POINTER(RawState), C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
     _LIB = L
   return _LIB
+
+
+class RingApi(C.Structure):
+  """Entry points of the encoder's arrival-ordered ring, handed to the stand-in engine as pointers."""
+  _fields_ = [("alloc_record", C.c_void_p), ("emit_record", C.c_void_p), ("record_done", C.c_void_p),
+              ("record_stride", C.c_void_p)]
+
+
+def ring_api():
+  from envpool_amd import capi_ygo
+  L = capi_ygo.lib()
+  addr = lambda f: C.cast(f, C.c_void_p).value
+  return RingApi(addr(L.ep_ygo_alloc_record), addr(L.ep_ygo_emit_record), addr(L.ep_ygo_record_done),
+                 addr(L.ep_ygo_record_stride))
+
+
+def run_producers(enc_handle, cfg, raw_states, n_envs, n_threads, steps_per_env, engine_us=0.0, sink_only=False):
+  """Blocks until the producer threads of the stand-in engine are done (call it from a thread of
+  its own next to the consumer; ctypes drops the GIL). Returns (status, seconds spent emitting)."""
+  api = ring_api()
+  emit = C.c_double()
+  rc = lib().ys_run_producers(enc_handle, C.byref(api), C.byref(cfg), raw_states, n_envs, n_threads, steps_per_env,
+                              engine_us, 1 if sink_only else 0, C.byref(emit))
+  return rc, emit.value
 
 
 def make_table(n=1000, seed=0):
