@@ -230,9 +230,23 @@ def main():
     k1_us = tot.value / max(1, cnt.value)
     per_step = {
       "value": N * ks / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / ks * 1e3,
-      "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
+      "kernel": "dummy_step_sp<10>", "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
+      "kernel_frac_of_hbm_peak": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
       "note": "ep_pool_send + blocking ep_pool_recv per lockstep step, device-resident actions",
     }
+    # the same blocking step without any launch: ep_pool_step's resident server kernel
+    for _ in range(64):
+      check(L.ep_pool_step(h, 5, p1, dims, C.byref(batch)))
+    kss = 8 * ks
+    s0 = time.perf_counter()
+    for _ in range(kss):
+      check(L.ep_pool_step(h, 5, p1, dims, C.byref(batch)))
+    s1 = time.perf_counter()
+    per_step["resident_server"] = {
+      "value": N * kss / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / kss * 1e3,
+      "GBps_incl_doorbell_round_trip": ALG_BYTES_PER_ENV_STEP * N * kss / (s1 - s0) / 1e9,
+      "note": "ep_pool_step: blocking step, no kernel launch (doorbell in host-mapped memory, resident kernel, sc1 loads/stores)"}
+    check(L.ep_pool_sync(h))
     # the same loop with the stream-ordered recv: batches are handed out as device views on the
     # pool's own stream (where a GPU-resident policy would run), the host never waits per step
     for _ in range(16):

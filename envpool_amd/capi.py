@@ -42,7 +42,7 @@ SYMBOLS = [
   "ep_pool_checkpoint_bytes", "ep_pool_checkpoint_save", "ep_pool_checkpoint_restore",
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
   "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
-  "ep_last_error", "ep_version", "ep_dummy_send_noalloc",
+  "ep_last_error", "ep_version", "ep_dummy_send_noalloc", "ep_pool_step", "ep_pool_last_rollout_kernel",
 ]
 
 _bound = None
@@ -61,6 +61,9 @@ def lib():
     L.ep_pool_recv_many.argtypes = [vp, i32, i32, C.POINTER(Batch)]
     L.ep_pool_recv_on_stream.argtypes = [vp, vp, C.POINTER(Batch)]
     L.ep_pool_set_recv_timeout.argtypes = [vp, i64]
+    L.ep_pool_step.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(Batch)]
+    L.ep_pool_last_rollout_kernel.argtypes = [vp]
+    L.ep_pool_last_rollout_kernel.restype = C.c_char_p
     L.ep_pool_episode_stats_async.argtypes = [vp, vp, vp, vp, vp]
     L.ep_batch_release.argtypes = [C.POINTER(Batch)]
     L.ep_pool_rollout.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]

@@ -1,0 +1,219 @@
+// dummy_server.hpp — the resident step server behind ep_pool_step.
+//
+// One launch per step costs 6.9 us on this platform before the kernel does anything (empty
+// kernel + completion event, tools/launch_floor.cpp): more than the 4.5 us step kernel itself.
+// A resident kernel that waits for a doorbell in host-mapped memory answers in 1.5 us (one
+// wave) to 5.6 us (256 workgroups woken through a device flag and joined through counters), so a
+// blocking step of a sync pool whose action arrays stay where they are can run without any
+// launch: the host writes the step number into the doorbell and spins on the word the last
+// workgroup writes back.
+//
+// What is computed per row is dummy_kernels.hpp's step_env (same reference citations). What
+// differs is memory visibility: the kernel outlives many steps while other kernels (the policy
+// that writes the next actions, the consumer of the rows) run between them, and the per-XCD L2s
+// are not coherent. So every byte this kernel reads that somebody else may have written since
+// its launch is read with sc1 (agent-scope) loads, and every byte it writes is stored sc1
+// (write-through): action arrays, env records, statistics, StateBuffer rows. Completion is
+// signalled after every wave's s_waitcnt vmcnt(0) and a workgroup barrier.
+//
+// It leaves by itself: on the quit bit, or when the doorbell has not rung for `idle_polls` polls
+// (about 50 ms), so a host that went away never leaves a spinning kernel behind.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dummy_kernels.hpp"
+
+namespace epk {
+
+#define EP_RLX_AGENT_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define EP_RLX_SYS_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+constexpr unsigned long long kServerQuit = 1ull << 32;  // doorbell / device flag: {step number : 32 | leave : 32}
+constexpr int kServerShards = 8;       // fan-in counters (each on a 128-byte line of its own)
+constexpr int kServerLineWords = 32;
+
+struct ServerCtl {  // host-mapped; one 128-byte line per direction
+  unsigned long long bell;  // host -> device: number of the last step requested (low word) | kServerQuit
+  uint32_t pad0[30];
+  uint32_t done;    // device -> host: number of the last step finished
+  uint32_t alive;   // device -> host: 0 once the kernel has decided to leave
+  uint32_t pad1[30];
+};
+
+struct ServerArgs {
+  ServerCtl* ctl;                 // device alias of the control block
+  unsigned long long* dev_flag;   // device: the step the leader has seen (low word) | kServerQuit: leave
+  uint32_t* counters;             // device: kServerShards shard counters + the global one, a line each, zero at launch
+  const int32_t* env_id;          // [N] action arrays, fixed for the life of this launch
+  const int32_t* players_env_id;  // [N]
+  const double* list_action;      // [N,6], 16-byte aligned
+  EnvRec* env;
+  StatPtrs stats;
+  RingLayout ring;
+  ErrWords* err;                  // device alias of the host-mapped error words
+  int32_t err_depth;
+  uint32_t* stamp;
+  PoolConst pc;
+  uint32_t first_step;            // the doorbell value of the first step this launch serves
+  uint64_t bi0;                   // batch index of that step
+  uint32_t idle_polls;
+  int32_t tiles_per_wg;           // N / 256 tiles dealt round robin over the workgroups
+  int32_t num_tiles;
+};
+
+__device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off, uint4 v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16);
+}
+
+template <int S_CT>
+__global__ __launch_bounds__(kBlock) void dummy_step_server(ServerArgs a) {
+  __shared__ Stage st;
+  __shared__ uint32_t s_go;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int S = S_CT > 0 ? S_CT : a.pc.S;
+  const uint32_t n_wg = gridDim.x;
+  const uint32_t shard = blockIdx.x % kServerShards;
+  const uint32_t shard_size = n_wg / kServerShards + (shard < n_wg % kServerShards ? 1u : 0u);
+  const uint32_t n_shards = n_wg < (uint32_t)kServerShards ? n_wg : (uint32_t)kServerShards;
+  const __amdgpu_buffer_rsrc_t la_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.list_action, 0, (int)((uint32_t)a.pc.N * 48u), 0x00020000);
+
+  for (uint32_t k = 0;; ++k) {
+    const uint32_t want = a.first_step + k;
+    // ---- wait for the doorbell ---------------------------------------------------------
+    if (tid == 0) {
+      uint32_t go = 0, polls = 0;
+      if (blockIdx.x == 0) {
+        for (;;) {
+          const unsigned long long b = __hip_atomic_load(&a.ctl->bell, EP_RLX_SYS_);
+          if (b & kServerQuit) break;
+          if ((int32_t)((uint32_t)b - want) >= 0) { go = 1; break; }
+          if (++polls > a.idle_polls) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(a.dev_flag, go ? (unsigned long long)want : kServerQuit, EP_RLX_AGENT_);
+        if (!go) __hip_atomic_store(&a.ctl->alive, 0u, EP_RLX_SYS_);
+      } else {
+        for (;;) {
+          const unsigned long long f = __hip_atomic_load(a.dev_flag, EP_RLX_AGENT_);
+          if (f & kServerQuit) break;
+          if ((int32_t)((uint32_t)f - want) >= 0) { go = 1; break; }
+          if (++polls > 64u * a.idle_polls) break;  // (the leader is gone: never spin for ever)
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return;
+
+    // ---- the step ------------------------------------------------------------------------
+    const uint64_t bi = a.bi0 + k;
+    const int slot = (int)(bi % (uint64_t)a.ring.depth);
+    ErrWords* const err = a.err + (int)(bi % (uint64_t)a.err_depth);
+    char* const slot_base = a.ring.ring + (uint64_t)slot * a.ring.stride;
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)slot_base, 0, (int)(uint32_t)a.ring.stride, 0x00020000);
+    for (int j = 0; j < a.tiles_per_wg; ++j) {
+      const int tile = (int)blockIdx.x + j * (int)n_wg;
+      if (tile >= a.num_tiles) break;
+      const int i = tile * kBlock + tid;
+      const int32_t eid = __hip_atomic_load(a.env_id + i, EP_RLX_AGENT_);
+      const int32_t penv = __hip_atomic_load(a.players_env_id + i, EP_RLX_AGENT_);
+      const uint4 l0 = ld16_sc1(la_rsrc, (uint32_t)i * 48u), l1 = ld16_sc1(la_rsrc, (uint32_t)i * 48u + 16u),
+                  l2 = ld16_sc1(la_rsrc, (uint32_t)i * 48u + 32u);
+      const int32_t local = eid - a.pc.env_off;
+      StepOut o;
+      if (local >= 0 && local < a.pc.N) {
+        unsigned long long* recp = reinterpret_cast<unsigned long long*>(a.env + local);
+        const unsigned long long rw = __hip_atomic_load(recp, EP_RLX_AGENT_);
+        EnvRec rec{(int32_t)(uint32_t)rw, (int32_t)(uint32_t)(rw >> 32)};
+        const double2 v0 = __builtin_bit_cast(double2, l0), v1 = __builtin_bit_cast(double2, l1),
+                      v2 = __builtin_bit_cast(double2, l2);
+        const bool ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        const int32_t L = episode_len(a.pc.seed, eid);
+        if (!ok && !(rec.state >= L)) __hip_atomic_store(&err->action_check, 1u, EP_RLX_SYS_);
+        if (stamp_seen(a.stamp, local, want | 0x40000000u)) __hip_atomic_store(&err->dup_env, 1u, EP_RLX_SYS_);
+        o = step_env(rec, eid, L, false, penv == eid ? 1 : 0, a.pc.max_episode_steps);
+        __hip_atomic_store(recp, (unsigned long long)(uint32_t)rec.state | ((unsigned long long)(uint32_t)rec.cur_step << 32),
+                           EP_RLX_AGENT_);
+        if (o.done) {  // episode statistics (rare; single player: every reward is +0.0f)
+          __hip_atomic_store(a.stats.fin_return + local, __hip_atomic_load(a.stats.ep_return + local, EP_RLX_AGENT_), EP_RLX_AGENT_);
+          __hip_atomic_store(a.stats.fin_length + local, o.elapsed, EP_RLX_AGENT_);
+          __hip_atomic_fetch_add(a.stats.ep_count + local, 1, EP_RLX_AGENT_);
+        }
+        if (o.elapsed == 0) __hip_atomic_store(a.stats.ep_return + local, 0.f, EP_RLX_AGENT_);
+      } else {
+        __hip_atomic_store(&err->env_id_range, 1u, EP_RLX_SYS_);
+        o.env_id = eid; o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0;
+      }
+      st.env_id[tid] = o.env_id;
+      st.elapsed[tid] = o.elapsed;
+      st.step_type[tid] = o.step_type;
+      st.state[tid] = o.state;
+      st.raw1[tid] = o.raw1;
+      st.discount[tid] = o.done ? 0.f : 1.f;
+      st.done[tid] = o.done;
+      st.trunc[tid] = o.trunc;
+      __syncthreads();
+      // the tile's rows: 256 consecutive rows from row tile*256, every key 16-byte aligned there.
+      // 4-byte keys: 1 KiB = one 16-byte store per lane of ONE wave; 1-byte keys: 16 lanes.
+      const uint32_t r4 = (uint32_t)tile * kBlock * 4u, r1 = (uint32_t)tile * kBlock;
+      auto put4 = [&](int key, const void* l) {
+        st16_sc1(out_rsrc, a.ring.off[key] + r4 + (uint32_t)lane * 16u, reinterpret_cast<const uint4*>(l)[lane]);
+      };
+      auto put1 = [&](int key, const uint8_t* l) {
+        if (lane < 16) st16_sc1(out_rsrc, a.ring.off[key] + r1 + (uint32_t)lane * 16u, reinterpret_cast<const uint4*>(l)[lane]);
+      };
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      if (wave == 0) {
+        put4(0, st.env_id);
+        put4(1, st.env_id);  // env.h:210-213: info:players.env_id[0] = env_id
+        put1(3, st.done);
+      } else if (wave == 1) {
+        put4(2, st.elapsed);
+        put4(6, st.step_type);
+        put1(7, st.trunc);
+      } else if (wave == 2) {
+        put4(5, st.discount);
+        put1(9, st.done);    // dummy_envpool.h:149/:201 players.done = IsDone()
+        st16_sc1(out_rsrc, a.ring.off[10] + r4 + (uint32_t)lane * 16u, z);  // players.id[0] = 0
+      } else {
+        st16_sc1(out_rsrc, a.ring.off[4] + r4 + (uint32_t)lane * 16u, z);   // reward[0] = float(-0) = +0.0f
+      }
+      // obs:raw: 256 rows x S ints, row r = {state, raw1, 0, ...}; 256*S*4 bytes is a multiple of 16
+      const int nvec = kBlock * S / 4;
+      const uint32_t raw0 = a.ring.off[8] + (uint32_t)tile * kBlock * (uint32_t)S * 4u;
+      for (int q = tid; q < nvec; q += kBlock) {
+        int e = q << 2;
+        int r = e / S;
+        int c = e - r * S;
+        uint32_t v[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          v[x] = (uint32_t)(c == 0 ? st.state[r] : (c == 1 ? st.raw1[r] : 0));
+          if (++c == S) { c = 0; ++r; }
+        }
+        st16_sc1(out_rsrc, raw0 + (uint32_t)q * 16u, make_uint4(v[0], v[1], v[2], v[3]));
+      }
+      __syncthreads();  // the stage is reused by the next tile
+    }
+    // ---- completion: every wave's stores have left, then one lane counts the workgroup in ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t old = __hip_atomic_fetch_add(a.counters + shard * kServerLineWords, 1u, EP_RLX_AGENT_);
+      if (old + 1 == (k + 1) * shard_size) {
+        const uint32_t g = __hip_atomic_fetch_add(a.counters + kServerShards * kServerLineWords, 1u, EP_RLX_AGENT_);
+        if (g + 1 == (k + 1) * n_shards) __hip_atomic_store(&a.ctl->done, want, EP_RLX_SYS_);
+      }
+    }
+  }
+}
+
+}  // namespace epk

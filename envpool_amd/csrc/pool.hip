@@ -34,6 +34,7 @@
 #include "dummy_kernels.hpp"
 #include "dummy_mp_kernels.hpp"
 #include "dummy_rollout_wave.hpp"
+#include "dummy_server.hpp"
 
 #include "common.hpp"
 
@@ -122,6 +123,16 @@ struct ep_pool {
   // copy_stream: ep_pool_sync only has to call hipStreamSynchronize (8-10 us even on an idle stream,
   // ROCm 7.2) when one of these is set or a launch is not yet known to have finished
   bool stream_extra = true, copy_dirty = true;
+  // resident step server (ep_pool_step, dummy_server.hpp)
+  hipStream_t server_stream = nullptr;
+  epk::ServerCtl* h_ctl = nullptr;  // host-mapped doorbell / answer lines
+  epk::ServerCtl* d_ctl = nullptr;
+  unsigned long long* d_server_words = nullptr;  // device flag line + fan-in counter lines
+  bool server_running = false;
+  uint32_t server_seq = 0;
+  const void* server_arrays[3]{};
+  int cu_count = 0;
+  bool use_server = true;  // EP_STEP_SERVER=0: ep_pool_step always takes the launch-per-step path
   bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
   int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
   bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
@@ -372,6 +383,61 @@ int claim_err_word(ep_pool* p, uint64_t bi) {
 uint32_t next_stamp(ep_pool* p) {  // stamp of the launch about to be enqueued: its id, never 0
   const uint32_t v = (uint32_t)(p->launch_seq + 1);
   return v ? v : 1u;
+}
+
+// ---- resident step server (dummy_server.hpp) ---------------------------------------------------
+// Asks a running server to leave and waits until its kernel has ended. Every entry point that
+// enqueues work on the pool's streams or reads the env state calls this first: while the server
+// runs, it alone owns the env records and the ring.
+int server_stop(ep_pool* p) {
+  if (!p->server_running) return EP_OK;
+  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq | epk::kServerQuit, __ATOMIC_RELEASE);
+  HIP_TRY(hipStreamSynchronize(p->server_stream));  // (the kernel leaves within a poll of seeing the flag, or has left already)
+  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq, __ATOMIC_RELEASE);
+  p->server_running = false;
+  return EP_OK;
+}
+
+// Starts the server for the action arrays `arrs` (env_id, players.env_id, list_action on the
+// device); the first step it serves is number server_seq + 1, batch index bi0.
+int server_start(ep_pool* p, const void* const* arrs) {
+  // everything the launch-per-step path has in flight must be finished: the server reads the env
+  // records those kernels write, and writes ring slots they may still be filling
+  HIP_TRY(hipStreamSynchronize(p->copy_stream));
+  if (int rc = sync_stream_unlocked(p, nullptr)) return rc;
+  HIP_TRY(hipMemsetAsync(p->d_server_words, 0, 128 * (2 + epk::kServerShards), p->server_stream));
+  p->h_ctl->alive = 1;
+  __atomic_store_n(&p->h_ctl->done, p->server_seq, __ATOMIC_RELEASE);
+  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq, __ATOMIC_RELEASE);
+  epk::ServerArgs a;
+  a.ctl = p->d_ctl;
+  a.dev_flag = p->d_server_words;
+  a.counters = reinterpret_cast<uint32_t*>(p->d_server_words + 16);  // the line after the flag's
+  a.env_id = (const int32_t*)arrs[0];
+  a.players_env_id = (const int32_t*)arrs[1];
+  a.list_action = (const double*)arrs[2];
+  a.env = p->d_env;
+  a.stats = p->stats;
+  a.ring.ring = p->d_ring;
+  a.ring.stride = p->slot_stride;
+  for (int k = 0; k < 11; ++k) a.ring.off[k] = (uint32_t)p->key_off[k];
+  a.ring.depth = p->Q;
+  a.err = p->d_err;
+  a.err_depth = p->EQ;
+  a.stamp = p->d_stamp;
+  a.pc = pool_const(p);
+  a.first_step = p->server_seq + 1;
+  a.bi0 = p->alloc_count / (uint64_t)p->B;
+  a.idle_polls = 40000;  // about 50 ms of doorbell polls
+  a.num_tiles = p->N / epk::kBlock;
+  const int n_wg = std::min(a.num_tiles, std::max(1, p->cu_count));
+  a.tiles_per_wg = (a.num_tiles + n_wg - 1) / n_wg;
+  if (p->S == 10) hipLaunchKernelGGL(epk::dummy_step_server<10>, dim3(n_wg), dim3(epk::kBlock), 0, p->server_stream, a);
+  else hipLaunchKernelGGL(epk::dummy_step_server<0>, dim3(n_wg), dim3(epk::kBlock), 0, p->server_stream, a);
+  HIP_TRY(hipGetLastError());
+  p->server_running = true;
+  for (int k = 0; k < 3; ++k) p->server_arrays[k] = arrs[k];
+  return EP_OK;
 }
 
 // Launch the single-player kernel for items [i0, i0+n) of one send/reset that land in `slot`
@@ -696,6 +762,13 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     HIP_TRY(hipEventCreateWithFlags(&p->stage_free[a], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->stage_copied[a], hipEventDisableTiming));
   }
+  HIP_TRY(hipStreamCreateWithFlags(&p->server_stream, hipStreamNonBlocking));
+  HIP_TRY(hipHostMalloc((void**)&p->h_ctl, sizeof(epk::ServerCtl), hipHostMallocMapped));
+  memset(p->h_ctl, 0, sizeof(epk::ServerCtl));
+  HIP_TRY(hipHostGetDevicePointer((void**)&p->d_ctl, p->h_ctl, 0));
+  HIP_TRY(hipMalloc((void**)&p->d_server_words, 128 * (2 + epk::kServerShards)));
+  HIP_TRY(hipDeviceGetAttribute(&p->cu_count, hipDeviceAttributeMultiprocessorCount, p->device));
+  if (const char* sv = getenv("EP_STEP_SERVER")) p->use_server = sv[0] != '0';
   p->slots.resize(p->Q);
   HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
@@ -712,8 +785,12 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
 int ep_pool_destroy(ep_pool* p) {
   if (!p) return EP_OK;
   (void)hipSetDevice(p->device);
+  (void)server_stop(p);
   (void)hipStreamSynchronize(p->stream);
   (void)hipStreamSynchronize(p->copy_stream);
+  if (p->server_stream) (void)hipStreamDestroy(p->server_stream);
+  if (p->h_ctl) (void)hipHostFree(p->h_ctl);
+  (void)hipFree(p->d_server_words);
   for (auto& ab : p->timed) { (void)hipEventDestroy(ab.first); (void)hipEventDestroy(ab.second); }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   for (auto& fe : p->inflight) (void)hipEventDestroy(fe.second);
@@ -752,6 +829,7 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   if (n == 0) return EP_OK;
   if (n > p->N) return fail(EP_ERR_INVALID, "reset of %d envs on a pool of %d", n, p->N);
   // (an env named twice in one reset is harmless: both items write the same record and the same rows)
@@ -784,6 +862,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   if (n == 0) return EP_OK;
   if (!arrays[0] || !arrays[1] || !arrays[2])
     return fail(EP_ERR_INVALID, "env_id, players.env_id and list_action must not be NULL");
@@ -881,6 +960,7 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   if (!p->is_sync)
     return fail(EP_ERR_INVALID, "rollout needs sync mode (batch_size == num_envs, max_num_players == 1)");
   if (T < 1 || T > p->Q) return fail(EP_ERR_INVALID, "rollout of %d steps needs 1 <= T <= ring_depth (%d)", T, p->Q);
@@ -991,6 +1071,7 @@ bool head_ready(ep_pool* p, int64_t* additional) {
 int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mutex>& lk,
                 hipStream_t* consumer = nullptr) {
   int rc = EP_OK;
+  if ((rc = server_stop(p))) return rc;
   int64_t additional = 0;
   if (!head_ready(p, &additional)) {
     auto would_block = [&]() {
@@ -1170,6 +1251,80 @@ int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   return status;
 }
 
+int ep_pool_step(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims, ep_batch* out) {
+  if (!p || !arrays || !leading_dims || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (n_arrays != 5) return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays in _action_keys order, got %d", n_arrays);
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    int rc = set_device(p);
+    if (rc) return rc;
+    const bool whole = leading_dims[0] == p->N && leading_dims[1] == p->N && leading_dims[2] == p->N;
+    const bool aligned = arrays[0] && arrays[1] && arrays[2] && !((uintptr_t)arrays[0] & 3) && !((uintptr_t)arrays[1] & 3) &&
+                         !((uintptr_t)arrays[2] & 15);
+    const bool idle = p->alloc_count == p->done_ptr * (uint64_t)p->B && p->stepping_env_num == 0;
+    if (p->use_server && !p->force_generic && p->is_sync && whole && aligned && idle && p->N % epk::kBlock == 0 && !p->poisoned) {
+      // ---- the resident server: no launch ---------------------------------------------
+      if (p->server_running && (p->server_arrays[0] != arrays[0] || p->server_arrays[1] != arrays[1] || p->server_arrays[2] != arrays[2]))
+        if ((rc = server_stop(p))) return rc;  // other action arrays: the server is started again for them
+      const uint64_t bi = p->alloc_count / (uint64_t)p->B;
+      if ((rc = claim_err_word(p, bi))) return rc;
+      if (!p->server_running && (rc = server_start(p, arrays))) return rc;
+      const uint32_t seq = ++p->server_seq;
+      __atomic_store_n(&p->h_ctl->bell, (unsigned long long)seq, __ATOMIC_RELEASE);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n(&p->h_ctl->done, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 1023u) == 1023u) {
+          if (__atomic_load_n(&p->h_ctl->alive, __ATOMIC_ACQUIRE) == 0) {
+            // the server left (its idle limit ran out as the doorbell rang): wait for its kernel to
+            // end; unless it answered on its way out, start a new one for this very step
+            HIP_TRY(hipStreamSynchronize(p->server_stream));
+            p->server_running = false;
+            if (__atomic_load_n(&p->h_ctl->done, __ATOMIC_ACQUIRE) == seq) break;
+            --p->server_seq;
+            if ((rc = server_start(p, arrays))) return rc;
+            ++p->server_seq;
+            __atomic_store_n(&p->h_ctl->bell, (unsigned long long)seq, __ATOMIC_RELEASE);
+          }
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            p->poisoned = true;
+            return fail(EP_ERR_HIP, "the step server did not answer within 5 s");
+          }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      const int slot = (int)(bi % (uint64_t)p->Q);
+      const int status = status_of_err_bits(take_err_bits(p, err_index(p, bi)), "step");
+      p->alloc_count += (uint64_t)p->B;  // one whole batch allocated ...
+      p->done_ptr += 1;                  // ... and received
+      memset(out, 0, sizeof(*out));
+      out->num_keys = 12;
+      out->mem = EP_MEM_DEVICE;
+      out->num_rows = p->N;
+      out->num_player_rows = p->N;
+      out->seq = p->recv_seq++;
+      char* base = p->d_ring + (size_t)slot * p->slot_stride;
+      for (int k = 0; k < 12; ++k) {
+        ep_array& a = out->arrays[k];
+        const int sk = kStateToSlot[k];
+        a.ndim = 1;
+        a.shape[0] = p->N;
+        if (sk < 0) { a.data = nullptr; a.dtype = EP_CONTAINER_I32; continue; }
+        a.data = base + p->key_off[sk];
+        a.dtype = kSlotDtype[sk];
+        if (sk == 8) { a.ndim = 2; a.shape[1] = p->S; }
+      }
+      return status;
+    }
+  }
+  // ---- anything else: one launch per step (send + blocking recv) ------------------------------
+  int rc = ep_pool_send(p, n_arrays, arrays, leading_dims, EP_MEM_DEVICE);
+  if (rc) return rc;
+  return ep_pool_recv(p, EP_MEM_DEVICE, out);
+}
+
 int ep_pool_set_recv_timeout(ep_pool* p, int64_t milliseconds) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->mu);
@@ -1183,6 +1338,7 @@ int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_leng
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   hipStream_t cs = (hipStream_t)consumer_stream;
   // destination buffers may still be read by the consumer's previous work (e.g. an all-gather)
   HIP_TRY(hipEventRecord(p->consumer_ev, cs));
@@ -1214,6 +1370,7 @@ int ep_pool_sync(ep_pool* p) {
   std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   if (p->copy_dirty) {
     p->copy_dirty = false;
     lk.unlock();
@@ -1238,6 +1395,7 @@ int ep_pool_episode_stats(ep_pool* p, float* fin_return, int32_t* fin_length, in
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   hipMemcpyKind kind = mem == EP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   size_t bytes = 4 * (size_t)p->N;
   if (fin_return) HIP_TRY(hipMemcpyAsync(fin_return, p->stats.fin_return, bytes, kind, p->stream));
@@ -1257,6 +1415,7 @@ int ep_pool_checkpoint_save(ep_pool* p, void* buf) {
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   char* o = (char*)buf;
   size_t n = (size_t)p->N;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1273,6 +1432,7 @@ int ep_pool_checkpoint_restore(ep_pool* p, const void* buf) {
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
+  if ((rc = server_stop(p))) return rc;
   const char* o = (const char*)buf;
   size_t n = (size_t)p->N;
   HIP_TRY(hipStreamSynchronize(p->stream));

@@ -157,6 +157,20 @@ int ep_pool_send(ep_pool* pool, int32_t n_arrays, const void* const* arrays,
  * env in a device-memory send (the batch is still returned in both cases). */
 int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
 
+/* One blocking lockstep step with device-resident actions: ep_pool_send(EP_MEM_DEVICE) followed
+ * by ep_pool_recv(EP_MEM_DEVICE) (envpool.py:135-142 step() = send + recv), as ONE call. For a sync
+ * pool stepped as a whole (every leading dim == num_envs, num_envs a multiple of 256, list_action
+ * 16-byte aligned, nothing else outstanding) no kernel is launched at all: a resident kernel of the
+ * pool (one workgroup per CU) waits on a doorbell in host-mapped memory, steps the envs and answers
+ * in a word the host spins on - one launch costs more than the step itself on this platform. The
+ * resident kernel is bound to the three action arrays it was started for (a step with other
+ * pointers restarts it), leaves by itself after about 50 ms without a step, and is stopped by any
+ * other entry point of the pool; results are those of send + recv, views valid as for
+ * ep_pool_recv(EP_MEM_DEVICE). Every other case takes the send + recv path. No counterpart in the
+ * reference beyond step() itself. */
+int ep_pool_step(ep_pool* pool, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims,
+                 ep_batch* out);
+
 /* How long ep_pool_recv / ep_pool_recv_many wait for env-steps that have not been sent yet:
  * < 0 (the default) for ever, as the reference does (a single-threaded caller that receives more
  * than it sent deadlocks there and here); 0 never - EP_ERR_WOULD_BLOCK at once; > 0 that many

@@ -258,3 +258,83 @@ def test_stream_ordered_error_words_survive_slot_reuse():
     assert L.ep_pool_recv(g.handle, capi.EP_MEM_DEVICE, C.byref(b)) == 0   # the later batches are clean
   assert L.ep_pool_sync(g.handle) == capi.EP_ERR_ACTION_CHECK
   assert L.ep_pool_sync(g.handle) == 0
+
+
+def _views(b, dev):
+  import torch  # noqa: F401
+
+  from envpool_amd import capi, interop
+  out = []
+  for k in range(b.num_keys):
+    a = b.arrays[k]
+    if a.dtype == capi.EP_CONTAINER_I32:
+      out.append(None)
+      continue
+    shape = tuple(a.shape[i] for i in range(a.ndim))
+    out.append(interop.as_torch((a.data, shape, np.dtype(capi._NP[a.dtype]).str), device=dev).cpu().numpy())
+  return out
+
+
+@pytest.mark.parametrize("n,steps", [(65536, 160), (1024, 400), (768, 60), (1000, 20)])
+def test_ep_pool_step_resident_server(n, steps):
+  """ep_pool_step: a blocking step with no kernel launch (resident server kernel, doorbell in
+  host-mapped memory). The action arrays are rewritten between steps by OTHER kernels (torch, on its
+  own stream) - what the server's sc1 loads have to see - and every step's rows are compared with
+  the oracle. In between: a launch-per-step send/recv, a fused rollout, a checkpoint, a change of
+  action arrays and an idle pause long enough for the server to leave by itself.
+  n = 1000 is not a multiple of 256: ep_pool_step takes the send + recv path there."""
+  import torch
+
+  from envpool_amd import capi
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  g, o = _pair(num_envs=n, seed=42 if n == 65536 else 3, ring_depth=4)
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  assert_batches_equal(g._recv(), o._recv(), "reset")
+  rng = np.random.default_rng(n)
+  t_ids = torch.from_numpy(ids).to(dev)
+  bufs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 6), dtype=torch.float64, device=dev)) for _ in range(2)]
+  dims = (C.c_int64 * 5)(n, n, n, n, n)
+  b = capi.Batch()
+  which = 0
+  for t in range(steps):
+    if t == steps // 2:
+      which = 1                      # other action arrays: the server is restarted for them
+    t_penv, t_la = bufs[which]
+    penv = ids + (rng.random(n) < 0.1).astype(np.int32)
+    lane = rng.integers(0, 5, size=(n, 1)).astype(np.float64)
+    # written on the device by torch kernels (H2D copy + elementwise kernels on torch's stream)
+    t_penv.copy_(torch.from_numpy(penv).to(dev) + 0)
+    t_la.copy_(torch.from_numpy(lane).to(dev).expand(n, 6) * 1.0)
+    torch.cuda.synchronize()
+    ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_penv.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr())
+    rc = L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b))
+    assert rc == 0, L.ep_last_error()
+    assert b.num_rows == n
+    o._send([ids, penv, np.repeat(lane, 6, axis=1), ids * 0, ids * 0])
+    assert_batches_equal(_views(b, dev), o._recv(), f"n={n} step {t}")
+    if t == 7:       # the launch-per-step path in between (stops the server)
+      a = dummy_action(rng.permutation(ids))
+      g._send(a); o._send(a)
+      assert_batches_equal(g._recv(), o._recv(), "send/recv in between")
+    if t == 11:      # a checkpoint reads the env state the server wrote
+      nb = L.ep_pool_checkpoint_bytes(g.handle)
+      buf = C.create_string_buffer(nb)
+      capi._check(L.ep_pool_checkpoint_save(g.handle, buf))
+      rec = np.frombuffer(buf.raw[: 8 * n], np.int32).reshape(n, 2)
+      want = o._recv()   # empty batch; the oracle's env state is checked through the next steps
+      assert len(want[0]) == 0 and rec[:, 1].min() >= 0
+    if t == 13:
+      time.sleep(0.25)   # longer than the server's idle limit: it leaves, the next step starts a new one
+  sr, sl, sc = g.episode_stats()
+  assert (sc >= 0).all() and not sr.any()
+  # a failed self-check is reported by the step it happened in
+  t_penv, t_la = bufs[which]
+  t_la.fill_(1.0)
+  t_la[5, 2] = 2.0
+  torch.cuda.synchronize()
+  ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_penv.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr())
+  rc = L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b))
+  assert rc in (capi.EP_ERR_ACTION_CHECK, 0)   # (0 when env 5 happened to be on its auto-reset step)
+  g.close()
