@@ -145,15 +145,10 @@ def main():
       check(L.ep_pool_rollout(h, chunks[i], 5, ptrs, dims, strides))  # next rollout queued ...
       recv_n(chunks[i - 1])                                           # ... while this one is received
       exchange_stats()
-    # the last launch: wait for the stream first (ep_pool_sync), then receive without waiting. The
-    # region ends in a device-wide synchronisation anyway, and a stream the runtime has seen idle
-    # costs that synchronisation nothing (9 us otherwise, a quarter of a 20-step region)
-    check(L.ep_pool_sync(h))
     recv_n(chunks[-1])
     p2 = time.perf_counter()
     exchange_stats()
-    if world > 1:
-      check(L.ep_pool_sync(h))
+    check(L.ep_pool_sync(h))
     if breakdown:
       phases.update(first_rollout_call_us=(p1 - p0) * 1e6, until_last_recv_us=(p2 - p1) * 1e6,
                     sync_us=(time.perf_counter() - p2) * 1e6)
@@ -167,16 +162,28 @@ def main():
   # Clock warm-up, independent of --warmup: after idling the shader clock needs some tens of
   # milliseconds of load to come up (the first ~150 launches after idle run 10-60 % slower), and a
   # short timed region would otherwise measure the ramp, not the kernel. Not part of the timed steps.
-  CLOCK_WARM_LAUNCHES = int(os.environ.get("EP_BENCH_CLOCK_WARM", "192"))
-  for _ in range(CLOCK_WARM_LAUNCHES):
-    run_fused(T)
+  # Few long launches (T steps each, queued back to back), not many short ones: a burst of a
+  # thousand 20-step launches leaves the runtime with a backlog of completed commands whose clean-up
+  # makes the next launches 15-25 us slower for the first millisecond (measured: 70 instead of 48 us
+  # per 20-step region). A kernel trace of a --steps 20 run therefore holds launches of two shapes
+  # under one kernel name; profiles/ splits them by duration.
+  CLOCK_WARM_MS = float(os.environ.get("EP_BENCH_CLOCK_WARM_MS", "30"))
+  warm_chunk = min(K, T) if os.environ.get("EP_BENCH_WARM_STYLE") == "same" else T
+  CLOCK_WARM_LAUNCHES = max(8, min(6000, int(CLOCK_WARM_MS * 1e-3 / (warm_chunk * 1.45e-6)) + 1))
+  check(L.ep_pool_rollout(h, warm_chunk, 5, ptrs, dims, strides))
+  for _ in range(CLOCK_WARM_LAUNCHES - 1):
+    check(L.ep_pool_rollout(h, warm_chunk, 5, ptrs, dims, strides))
+    recv_n(warm_chunk)
+  recv_n(warm_chunk)
+  check(L.ep_pool_sync(h))
   tot = C.c_double()
   cnt = C.c_int64()
   R = max(1, args.repeats)
   # The K-step region, R times; each run is bracketed by barrier + synchronize on both sides and
   # times exactly K lockstep steps. The line reports the MEDIAN run (max over ranks per run).
   walls, kern = [], []
-  for r in range(R):
+  REHEARSALS = 4  # untimed runs of the same region first: the pool creates its timing events in them
+  for r in range(-REHEARSALS, R):
     check(L.ep_pool_set_timing(h, 1))
     check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
     barrier()
@@ -186,6 +193,8 @@ def main():
     t1 = time.perf_counter()
     check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
     check(L.ep_pool_set_timing(h, 0))
+    if r < 0:
+      continue
     walls.append(t1 - t0)
     kern.append((tot.value, max(1, cnt.value)))
     if breakdown and rank == 0:
@@ -263,6 +272,45 @@ def main():
     per_step["stream_ordered"] = {
       "value": N * kso / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / kso * 1e3,
       "note": "ep_pool_send + ep_pool_recv_on_stream per lockstep step (no host wait inside the loop)"}
+
+  # multi-player pools (ragged player dimension): 3 players max, every env sent back each step with
+  # one action row per player it reported (the previous batch's info:players.env_id, a device view)
+  if rank == 0 and world == 1:
+    try:
+      mp = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=dev_index, max_num_players=3, ring_depth=4)
+      hm = mp.handle
+      check(L.ep_pool_reset(hm, env_id.data_ptr(), N, capi.EP_MEM_DEVICE))
+      check(L.ep_pool_recv(hm, capi.EP_MEM_DEVICE, C.byref(batch)))
+      la_mp = la[0].contiguous()
+
+      def mp_step():
+        rows = batch.num_player_rows
+        pm = (C.c_void_p * 5)(env_id.data_ptr(), batch.arrays[1].data, la_mp.data_ptr(), unused.data_ptr(), unused.data_ptr())
+        dm = (C.c_int64 * 5)(N, rows, N, rows, rows)
+        check(L.ep_pool_send(hm, 5, pm, dm, capi.EP_MEM_DEVICE))
+        check(L.ep_pool_recv(hm, capi.EP_MEM_DEVICE, C.byref(batch)))
+        return rows
+      for _ in range(32):
+        mp_step()
+      km = 256
+      s0 = time.perf_counter()
+      prow = 0
+      for _ in range(km):
+        prow += mp_step()
+      s1 = time.perf_counter()
+      check(L.ep_pool_set_timing(hm, 1))
+      check(L.ep_pool_kernel_time_us(hm, C.byref(tot), C.byref(cnt), 1))
+      for _ in range(64):
+        mp_step()
+      check(L.ep_pool_kernel_time_us(hm, C.byref(tot), C.byref(cnt), 1))
+      per_step["multiplayer_P3"] = {
+        "value": N * km / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / km * 1e3,
+        "player_rows_per_step": prow / km, "fused_kernel_us": tot.value / max(1, cnt.value),
+        "note": "max_num_players=3: histogram kernel + fused step / look-back scan / player-row kernel per send, "
+                "player total through a host-mapped word (no blocking copy in recv)"}
+      mp.close()
+    except Exception as ex:  # noqa: BLE001
+      per_step["multiplayer_P3"] = {"error": repr(ex)}
 
   # the boundary also takes host buffers (the reference's numpy path): PCIe-inclusive rate,
   # host actions in, host StateBuffer out, one launch per step. Reported, never `value`.
@@ -345,6 +393,7 @@ def main():
         "config3_kernel_us": c3["kernel_us"], "config3_zero_copy": c3.get("zero_copy"),
         "config3_staging_copy_us": c3["h2d_copy_us"],
         "host_emit_records_per_s_1core": r["host_emit_records_per_s_1core"],
+        "config3_packed": r.get("config3_packed"),
         "config5_async_ring": r.get("config5_async_ring"),
       }
       if "cpu_oracle_encodes_per_s_1core" in r:
@@ -403,7 +452,7 @@ def main():
     line = {
       "metric": "env-steps/sec (whole node) Dummy-v0", "value": world * N * K / elapsed, "unit": "env-steps/s",
       "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-      "repeats": R, "clock_warm_launches": CLOCK_WARM_LAUNCHES,
+      "repeats": R, "clock_warm_launches": CLOCK_WARM_LAUNCHES, "untimed_rehearsals": REHEARSALS,
       "ms_per_step_all_runs": [w / K * 1e3 for w in walls],
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
       "data": "synthetic",

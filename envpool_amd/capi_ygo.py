@@ -52,7 +52,8 @@ SYMBOLS = [
   "ep_ygo_commit_slot", "ep_ygo_sync", "ep_ygo_stream", "ep_ygo_set_timing", "ep_ygo_kernel_time_us",
   "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy", "ep_ygo_submit_device",
   "ep_ygo_async_begin", "ep_ygo_alloc_record", "ep_ygo_record_done", "ep_ygo_recv", "ep_ygo_set_recv_timeout",
-  "ep_ygo_ring_stats",
+  "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
+  "ep_ygo_commit_slot_packed", "ep_ygo_emit_records_packed",
 ]
 
 _bound = None
@@ -89,6 +90,13 @@ def lib():
     L.ep_ygo_record_done.argtypes = [vp, C.c_uint64]
     L.ep_ygo_recv.argtypes = [vp, i32, C.POINTER(capi.Batch)]
     L.ep_ygo_set_recv_timeout.argtypes = [vp, i64]
+    L.ep_ygo_set_packed.argtypes = [vp, i32]
+    L.ep_ygo_emit_arrival.argtypes = [vp, C.POINTER(RawState)]
+    L.ep_ygo_put_arrival.argtypes = [vp, vp]
+    L.ep_ygo_record_used_bytes.argtypes = [C.POINTER(YgoConfig), vp]
+    L.ep_ygo_record_used_bytes.restype = i64
+    L.ep_ygo_commit_slot_packed.argtypes = [vp, i32, vp, i64]
+    L.ep_ygo_emit_records_packed.argtypes = [vp, C.POINTER(RawState), i32, vp]
     L.ep_ygo_ring_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ep_ygo_history_push.argtypes = [C.POINTER(YgoConfig), vp, C.POINTER(i32), i32, C.c_char_p, vp, i32]
     _bound = L

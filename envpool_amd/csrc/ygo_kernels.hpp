@@ -105,6 +105,7 @@ __host__ __device__ inline Carve carve(int max_cards, int max_options, int n_his
 
 struct Args {
   const uint8_t* records;
+  const uint32_t* offsets;  // packed records: byte offset of record i from `records` (16-byte aligned); null: i * stride
   int64_t stride;
   int32_t n;
   const HashEntry* table;
@@ -299,7 +300,12 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
   //   records in pinned host memory (the kernel reads them over PCIe itself, a.lean_fetch): nothing
   //     before the header; then exactly the history ring with the used options, and the listed
   //     cards, each span to its own place in the landing area - every byte saved is PCIe time.
-  const uint8_t* const rec = a.records + e * a.stride;
+  const uint8_t* rec_at = a.records + e * a.stride;
+  if (a.offsets) {  // packed batch: records back to back, in the order their producers finished
+    typedef const __attribute__((address_space(4))) uint32_t* KOff;
+    rec_at = a.records + ((KOff)(uintptr_t)a.offsets)[e];  // e is wave-uniform: a scalar load
+  }
+  const uint8_t* const rec = rec_at;
   auto fetch_span = [&](int first_piece, int n_pieces, int c_lo) {  // pieces [first, first + n) -> stage + 16*first
     for (int c = c_lo; 64 * c < n_pieces; ++c) {
       const int piece = first_piece + min(lane + 64 * c, n_pieces - 1);

@@ -192,6 +192,26 @@ int ep_ygo_alloc_record(ep_ygo_encoder* enc, void** record, uint64_t* ticket);
 int ep_ygo_record_done(ep_ygo_encoder* enc, uint64_t ticket);
 int ep_ygo_recv(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);
 int ep_ygo_set_recv_timeout(ep_ygo_encoder* enc, int64_t milliseconds);
+/* Packed form of the arrival-ordered ring (after ep_ygo_async_begin): records lie back to back in
+ * the pinned slot in the order their producers finished, with a per-row offset table in front, and
+ * the batch reaches the device as ONE copy-engine transfer of exactly the bytes in use (about 1.6 KB
+ * per mid-game record instead of the 3328-byte stride; large PCIe reads instead of the kernel's own
+ * 64-byte ones).
+ *   ep_ygo_set_packed       switches the form (no record may be outstanding)
+ *   ep_ygo_emit_arrival     one call per finished env-step from any thread: ep_ygo_emit_record into
+ *                           a thread-local buffer, then row + bytes are taken in arrival order
+ *                           (two atomic adds), the record is copied in and reported done
+ *   ep_ygo_put_arrival      the same for a record that has been emitted already
+ *   ep_ygo_record_used_bytes  the length of the used prefix of a record (16-byte multiple)
+ * Batches are received with ep_ygo_recv. Results are identical in every form. */
+int ep_ygo_set_packed(ep_ygo_encoder* enc, int32_t enabled);
+int ep_ygo_put_arrival(ep_ygo_encoder* enc, const void* record);
+int64_t ep_ygo_record_used_bytes(const ep_ygo_config* cfg, const void* record);
+/* The packed form for ONE producer (submit / collect mode): the caller fills the slot it got from
+ * ep_ygo_acquire_slot with n records back to back (record i at byte offsets[i], 16-byte aligned,
+ * used_bytes in all) and commits; or lets ep_ygo_emit_records_packed (below, with the raw-state
+ * type) emit n states that way. Collected with ep_ygo_collect like any other batch. */
+int ep_ygo_commit_slot_packed(ep_ygo_encoder* enc, int32_t n, const uint32_t* offsets, int64_t used_bytes);
 /* Counters of the arrival-ordered ring since ep_ygo_async_begin: the time producer threads spent
  * waiting for a free slot (the only place where the GPU side can hold the duel threads up), the
  * records handed out and the batches received. Any pointer may be NULL. */
@@ -233,6 +253,12 @@ typedef struct {
  * (grammar of _set_obs_action, :1674-1765) into one record. Host only, no GPU. Returns
  * EP_ERR_INVALID on input the reference would throw on while parsing. */
 int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
+
+/* Packed arrival-ordered ring, one call per finished env-step (see ep_ygo_set_packed above). */
+int ep_ygo_emit_arrival(ep_ygo_encoder* enc, const ygo_raw_state* in);
+
+/* acquire + n packed emits + commit for a single producer (see ep_ygo_commit_slot_packed). */
+int ep_ygo_emit_records_packed(ep_ygo_encoder* enc, const ygo_raw_state* in, int32_t n, int32_t* status);
 
 /* `n` consecutive ep_ygo_emit_record calls; record i goes to records_out + i*stride.
  * status[i] (may be NULL) receives each call's code; returns the first non-OK code. */

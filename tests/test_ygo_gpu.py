@@ -306,8 +306,8 @@ def test_full_size_batch_properties():
   assert acc == checksum(got)
 
 
-@pytest.mark.parametrize("threads,zero_copy", [(1, 1), (4, 1), (7, 0)])
-def test_arrival_ordered_ring_with_producer_threads(threads, zero_copy):
+@pytest.mark.parametrize("threads,zero_copy,packed", [(1, 1, 0), (4, 1, 0), (7, 0, 0), (5, 1, 1), (2, 0, 1)])
+def test_arrival_ordered_ring_with_producer_threads(threads, zero_copy, packed):
   """BASELINE config 5's shape on one GPU (1024 envs, 512-record batches): host producer threads
   emit records in place into rows handed out in ARRIVAL order (the YGO analogue of
   state_buffer_queue.h:114-128 + state_buffer.h:79-129), the batch is encoded when its 512th record
@@ -328,8 +328,11 @@ def test_arrival_ordered_ring_with_producer_threads(threads, zero_copy):
   capi._check(L.ep_ygo_set_zero_copy(enc.handle, zero_copy))
   capi._check(L.ep_ygo_async_begin(enc.handle, B))
   capi._check(L.ep_ygo_set_recv_timeout(enc.handle, 30000))
+  # packed: records back to back in arrival order + offset table, one copy-engine transfer per batch
+  capi._check(L.ep_ygo_set_packed(enc.handle, packed))
+  mode = ygo_synth.PACKED_EMIT if packed else ygo_synth.RING_IN_PLACE
   res = {}
-  prod = threading.Thread(target=lambda: res.update(rc=ygo_synth.run_producers(enc.handle, cfg, sb.raw, N, threads, steps, engine_us=2.0)))
+  prod = threading.Thread(target=lambda: res.update(rc=ygo_synth.run_producers(enc.handle, cfg, sb.raw, N, threads, steps, engine_us=2.0, mode=mode)))
   prod.start()
   got = {}
   for bi in range(N * steps // B):
@@ -391,3 +394,44 @@ def test_featurize_returns_its_own_batch():
   b = enc.featurize(rb, allow=(capi.EP_ERR_ACTION_CHECK,))
   assert a[0].tolist() == [int(sa.raw[i].env_id) for i in range(8)]
   assert b[0].tolist() == [int(sb.raw[i].env_id) for i in range(8)]
+
+
+def test_single_producer_packed_slot():
+  """Submit / collect mode with the slot filled in the packed form (records back to back + offset
+  table, one copy-engine transfer of the bytes in use): ep_ygo_emit_records_packed, and
+  ep_ygo_commit_slot_packed with a caller-packed slot, against the oracle."""
+  import ctypes as C
+
+  from envpool_amd import capi
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  n = 700
+  cfg = capi_ygo.default_config(max_batch=1024, ring_depth=3)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, n, seed=21)
+  want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
+  rows = np.nonzero(status == 0)[0]
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  L = capi_ygo.lib()
+  est = np.zeros(n, np.int32)
+  capi._check(L.ep_ygo_emit_records_packed(enc.handle, sb.raw, n, est.ctypes.data))
+  assert (est == 0).all()
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, "emit_records_packed")
+  # the caller packs: used prefixes of fixed-stride records, in REVERSE order in the slot
+  recs, _ = capi_ygo.emit_records(cfg, sb.raw, n)
+  lens = [L.ep_ygo_record_used_bytes(C.byref(cfg), recs[i].ctypes.data) for i in range(n)]
+  assert all(x % 16 == 0 and 64 <= x <= recs.shape[1] for x in lens) and sum(lens) < 0.7 * recs.size
+  slot = C.c_void_p()
+  capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
+  offs = np.zeros(n, np.uint32)
+  pos = 0
+  for i in reversed(range(n)):
+    C.memmove(slot.value + pos, recs[i].ctypes.data, lens[i])
+    offs[i] = pos
+    pos += lens[i]
+  capi._check(L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos))
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, "commit_slot_packed")
+  offs[3] += 4
+  capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
+  assert L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos) == capi.EP_ERR_INVALID
+  enc.close()

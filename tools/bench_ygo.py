@@ -161,6 +161,10 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
   res = {"large_batch": big_res, "config3_host_pipeline": cfg3_res, "config5_per_gpu_host_pipeline": cfg5_res,
          "host_emit_records_per_s_1core": n_gen / emit_s}
   try:
+    res["config3_packed"] = run_config3_packed(device)
+  except Exception as ex:  # noqa: BLE001
+    res["config3_packed"] = {"error": repr(ex)}
+  try:
     res["config5_async_ring"] = run_config5(device)
   except Exception as ex:  # noqa: BLE001
     res["config5_async_ring"] = {"error": repr(ex)}
@@ -242,6 +246,91 @@ def run_config5(device=0, threads_list=(1, 4, 12, 16), n_envs=1024, batch=512, s
       "gpu_kernel_s": gpu_s, "kernel_us_per_batch": tot.value / max(1, cnt.value),
       "emit_us_per_record": res["r"][1] / recs_n * 1e6, "producer_wait_for_slot_s": wait_s.value, "tail_s": tail_s,
       "gpu_time_hidden_behind_emission": hidden}
+    enc.close()
+  return out
+
+def run_config3_packed(device=0, n_envs=1024, steps_per_env=100, threads=4):
+  """BASELINE config 3 (1024 envs, sync: batch = 1024) with host records in the PACKED form:
+  producer threads hand finished records (emitted beforehand: the duel engine and the emitter are
+  not what is measured here) to the arrival-ordered ring, each batch reaches the device as one
+  copy-engine transfer of the bytes in use, the encode kernel reads HBM. PCIe-inclusive."""
+  import threading
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  L = capi_ygo.lib()
+  cfg = capi_ygo.default_config(max_batch=n_envs, ring_depth=4, device_id=device)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, n_envs, seed=0)
+  recs, _ = capi_ygo.emit_records(cfg, sb.raw, n_envs)
+  used = sum(L.ep_ygo_record_used_bytes(C.byref(cfg), recs[i].ctypes.data) for i in range(n_envs))
+  tot, cnt = C.c_double(), C.c_int64()
+  b = capi.Batch()
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  out = {"envs": n_envs, "batch_size": n_envs, "producer_threads": threads, "bytes_per_record_packed": used / n_envs,
+         "bytes_per_record_fixed_stride": int(recs.shape[1])}
+  # (1) the pipeline by itself: slots already filled in the packed form (as config3_host_pipeline's
+  # in-place figure has them filled at the fixed stride), commit + collect with 3 batches in flight
+  import numpy as np
+  lens = np.array([L.ep_ygo_record_used_bytes(C.byref(cfg), recs[i].ctypes.data) for i in range(n_envs)], np.int64)
+  offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32)
+  packed_buf = np.concatenate([recs[i, :lens[i]] for i in range(n_envs)])
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  h = enc.handle
+  slot = C.c_void_p()
+  for _ in range(4):
+    assert L.ep_ygo_acquire_slot(h, C.byref(slot)) == 0
+    C.memmove(slot, packed_buf.ctypes.data, packed_buf.nbytes)
+    assert L.ep_ygo_commit_slot_packed(h, n_envs, offs.ctypes.data, int(used)) == 0
+    assert L.ep_ygo_collect(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  L.ep_ygo_set_timing(h, 1)
+  L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+  steps = 400
+  i0 = time.perf_counter()
+  inflight = 0
+  for _ in range(steps):
+    assert L.ep_ygo_acquire_slot(h, C.byref(slot)) == 0
+    assert L.ep_ygo_commit_slot_packed(h, n_envs, offs.ctypes.data, int(used)) == 0
+    inflight += 1
+    if inflight == 3:
+      assert L.ep_ygo_collect(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      inflight -= 1
+  while inflight:
+    assert L.ep_ygo_collect(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    inflight -= 1
+  i1 = time.perf_counter()
+  L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+  out["pipeline_slots_prefilled"] = {"us_per_step_wall": (i1 - i0) / steps * 1e6,
+                                     "encodes_per_s_pcie_inclusive": n_envs * steps / (i1 - i0),
+                                     "kernel_us": tot.value / max(1, cnt.value),
+                                     "copy_GBps": (used + 4096) / ((i1 - i0) / steps) / 1e9}
+  enc.close()
+  # (2) with producer threads handing finished records over
+  for name, packed, zero_copy, mode in (("packed_copy_engine", 1, 0, ygo_synth.PACKED_PUT),):
+    enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+    h = enc.handle
+    assert L.ep_ygo_set_zero_copy(h, zero_copy) == 0
+    assert L.ep_ygo_async_begin(h, n_envs) == 0
+    assert L.ep_ygo_set_packed(h, packed) == 0
+    L.ep_ygo_set_timing(h, 1)
+    L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+    res = {}
+    th = threading.Thread(target=lambda: res.update(r=ygo_synth.run_producers(h, cfg, sb.raw, n_envs, threads, steps_per_env, 0.0,
+                                                                             mode=mode, pre_records=recs)))
+    w0 = time.perf_counter()
+    th.start()
+    for _ in range(steps_per_env):
+      assert L.ep_ygo_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    wall = time.perf_counter() - w0
+    th.join()
+    assert res["r"][0] == 0
+    L.ep_ygo_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1)
+    wait_s = C.c_double()
+    L.ep_ygo_ring_stats(h, C.byref(wait_s), None, None)
+    out[name] = {"us_per_step_wall": wall / steps_per_env * 1e6, "encodes_per_s_pcie_inclusive": n_envs * steps_per_env / wall,
+                 "kernel_us": tot.value / max(1, cnt.value), "producer_put_us_per_record": res["r"][1] / (n_envs * steps_per_env) * 1e6,
+                 "producer_wait_for_slot_s": wait_s.value}
     enc.close()
   return out
 

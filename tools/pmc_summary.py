@@ -30,8 +30,13 @@ def main():
     if "Start_Timestamp" in cols and "Kernel_Name" in cols and "Counter_Name" not in cols:
       d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if keep(r)]
       if d:
-        out.setdefault("trace", {})[os.path.relpath(path, root)] = {
-          "calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+        entry = {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+        split = float(os.environ.get("PMC_SUMMARY_SPLIT_NS", "0"))
+        if split > 0:  # launches of two shapes under one name (bench.py --steps 20: clock warm-up vs timed)
+          for name, sel in (("shorter", [x for x in d if x < split]), ("longer", [x for x in d if x >= split])):
+            if sel:
+              entry[name + f"_than_{int(split)}ns"] = {"calls": len(sel), "avg_ns": sum(sel) / len(sel), "min_ns": min(sel), "max_ns": max(sel)}
+        out.setdefault("trace", {})[os.path.relpath(path, root)] = entry
     if "Counter_Name" in cols and "Counter_Value" in cols:
       acc = {}
       for r in rows:

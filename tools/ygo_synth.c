@@ -353,7 +353,12 @@ typedef struct {
   int (*emit_record)(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
   int (*record_done)(void* enc, uint64_t ticket);
   int64_t (*record_stride)(const ep_ygo_config* cfg);
+  int (*emit_arrival)(void* enc, const ygo_raw_state* in);  /* packed form: alloc + emit + done in one call */
+  int (*put_arrival)(void* enc, const void* record);        /* packed form, record emitted beforehand */
 } ys_ring_api;
+
+/* sink_only argument of ys_run_producers: how a finished env-step reaches the encoder */
+enum { YS_RING_IN_PLACE = 0, YS_SINK = 1, YS_PACKED_EMIT = 2, YS_PACKED_PUT = 3 };
 
 typedef struct {
   void* enc;
@@ -364,6 +369,7 @@ typedef struct {
   double engine_us;
   int rc;
   double emit_seconds; /* time inside alloc + emit + done */
+  const uint8_t* pre_records; /* YS_PACKED_PUT: n_envs records emitted beforehand, at the fixed stride */
 } ys_prod_arg;
 
 static double ys_now(void) {
@@ -375,7 +381,8 @@ static double ys_now(void) {
 static void* ys_producer(void* v) {
   ys_prod_arg* a = (ys_prod_arg*)v;
   void* scratch = NULL;
-  if (a->sink_only) scratch = malloc((size_t)a->api->record_stride(a->cfg));
+  const int64_t stride = a->api->record_stride(a->cfg);
+  if (a->sink_only == YS_SINK || a->sink_only == YS_PACKED_PUT) scratch = malloc((size_t)stride);
   for (int s = 0; s < a->steps_per_env && a->rc == 0; ++s) {
     for (int e = a->tid; e < a->n_envs && a->rc == 0; e += a->n_threads) {
       if (a->engine_us > 0) {
@@ -385,6 +392,26 @@ static void* ys_producer(void* v) {
       ygo_raw_state st = a->states[e]; /* shallow copy: the buffers it points into are read-only */
       st.elapsed_step = s;
       const double t0 = ys_now();
+      if (a->sink_only == YS_PACKED_EMIT) {
+        int prc = a->api->emit_arrival(a->enc, &st);
+        if (prc != 0) {
+          ygo_raw_state empty = st;
+          empty.n_options = 0;
+          prc = a->api->emit_arrival(a->enc, &empty);
+        }
+        a->rc = prc;
+        a->emit_seconds += ys_now() - t0;
+        continue;
+      }
+      if (a->sink_only == YS_PACKED_PUT) {
+        /* the record exists already (the engine + emitter cost is not what is measured): stamp the
+         * step into its header copy and hand it over */
+        memcpy(scratch, a->pre_records + (size_t)e * (size_t)stride, (size_t)stride);
+        ((ygo_header*)scratch)->elapsed_step = s;
+        a->rc = a->api->put_arrival(a->enc, scratch);
+        a->emit_seconds += ys_now() - t0;
+        continue;
+      }
       void* rec = scratch;
       uint64_t ticket = 0;
       if (!a->sink_only && (a->rc = a->api->alloc_record(a->enc, &rec, &ticket)) != 0) break;
@@ -405,14 +432,14 @@ static void* ys_producer(void* v) {
 
 int ys_run_producers(void* enc, const ys_ring_api* api, const ep_ygo_config* cfg, const ygo_raw_state* states,
                      int32_t n_envs, int32_t n_threads, int32_t steps_per_env, double engine_us, int32_t sink_only,
-                     double* emit_seconds_out) {
+                     double* emit_seconds_out, const uint8_t* pre_records) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;
   pthread_t th[64];
   ys_prod_arg arg[64];
   int started = 0, rc = 0;
   for (int t = 0; t < n_threads; ++t) {
-    arg[t] = (ys_prod_arg){enc, api, cfg, states, n_envs, n_threads, t, steps_per_env, sink_only, engine_us, 0, 0.0};
+    arg[t] = (ys_prod_arg){enc, api, cfg, states, n_envs, n_threads, t, steps_per_env, sink_only, engine_us, 0, 0.0, pre_records};
     if (pthread_create(&th[t], NULL, ys_producer, &arg[t]) != 0) { rc = -1; break; }
     ++started;
   }

@@ -22,7 +22,7 @@ def lib():
                                C.POINTER(RawState)]
     L.ys_free_batch.argtypes = [C.c_void_p, C.c_int32]
     L.ys_run_producers.argtypes = [C.c_void_p, C.POINTER(RingApi), C.POINTER(YgoConfig), C.POINTER(RawState), C.c_int32,
-                                   C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
+                                   C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double), C.c_void_p]
     _LIB = L
   return _LIB
 
@@ -30,7 +30,10 @@ def lib():
 class RingApi(C.Structure):
   """Entry points of the encoder's arrival-ordered ring, handed to the stand-in engine as pointers."""
   _fields_ = [("alloc_record", C.c_void_p), ("emit_record", C.c_void_p), ("record_done", C.c_void_p),
-              ("record_stride", C.c_void_p)]
+              ("record_stride", C.c_void_p), ("emit_arrival", C.c_void_p), ("put_arrival", C.c_void_p)]
+
+
+RING_IN_PLACE, SINK, PACKED_EMIT, PACKED_PUT = 0, 1, 2, 3  # how a finished env-step reaches the encoder
 
 
 def ring_api():
@@ -38,16 +41,22 @@ def ring_api():
   L = capi_ygo.lib()
   addr = lambda f: C.cast(f, C.c_void_p).value
   return RingApi(addr(L.ep_ygo_alloc_record), addr(L.ep_ygo_emit_record), addr(L.ep_ygo_record_done),
-                 addr(L.ep_ygo_record_stride))
+                 addr(L.ep_ygo_record_stride), addr(L.ep_ygo_emit_arrival), addr(L.ep_ygo_put_arrival))
 
 
-def run_producers(enc_handle, cfg, raw_states, n_envs, n_threads, steps_per_env, engine_us=0.0, sink_only=False):
+def run_producers(enc_handle, cfg, raw_states, n_envs, n_threads, steps_per_env, engine_us=0.0, sink_only=False,
+                  mode=None, pre_records=None):
   """Blocks until the producer threads of the stand-in engine are done (call it from a thread of
-  its own next to the consumer; ctypes drops the GIL). Returns (status, seconds spent emitting)."""
+  its own next to the consumer; ctypes drops the GIL). `mode`: RING_IN_PLACE (default), SINK,
+  PACKED_EMIT or PACKED_PUT (`pre_records`: uint8 [n_envs, stride] emitted beforehand).
+  Returns (status, seconds spent emitting)."""
   api = ring_api()
   emit = C.c_double()
+  if mode is None:
+    mode = SINK if sink_only else RING_IN_PLACE
+  pre = pre_records.ctypes.data if pre_records is not None else None
   rc = lib().ys_run_producers(enc_handle, C.byref(api), C.byref(cfg), raw_states, n_envs, n_threads, steps_per_env,
-                              engine_us, 1 if sink_only else 0, C.byref(emit))
+                              engine_us, mode, C.byref(emit), pre)
   return rc, emit.value
 
 
