@@ -338,7 +338,7 @@ def main():
 
   cpu = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    from oracle.dummy_oracle import DummyOracle, bench_sync_mt
+    from oracle.dummy_oracle import DummyOracle, bench_sync_mt, bench_sync_threadpool
     o = DummyOracle(num_envs=N, seed=SEED)
     c0 = time.perf_counter()
     o.bench_sync(40)
@@ -360,9 +360,27 @@ def main():
     c0 = time.perf_counter()
     bench_sync_mt(N, SEED, n_cpu, cores)
     c1 = time.perf_counter()
+    # the same workload through the reference's ARCHITECTURE (oracle/dummy_pool_mt.c: action queue
+    # -> worker threads -> state-buffer queue, fresh zeroed buffer per batch): ~3 s per thread count
+    arch = {}
+    for th in (1, cores):
+      c2 = time.perf_counter()
+      bench_sync_threadpool(N, SEED, 3, th)
+      per_step = (time.perf_counter() - c2) / 4
+      n_arch = int(max(4, min(2000, 3.0 / per_step)))
+      c2 = time.perf_counter()
+      bench_sync_threadpool(N, SEED, n_arch, th)
+      arch[str(th)] = N * (n_arch + 1) / (time.perf_counter() - c2)
     cpu = {
       "value": N * n_cpu / (c1 - c0), "unit": "env-steps/s", "cores": cores, "kind": "port",
       "single_thread_value": single,
+      "reference_architecture": {
+        "value_by_worker_threads": arch, "unit": "env-steps/s",
+        "note": "oracle/dummy_pool_mt.c: the reference's ActionBufferQueue -> worker threads -> "
+                "StateBufferQueue restated with pthreads and a spin-then-futex semaphore; every "
+                "env-step crosses the queue's two semaphores (action_buffer_queue.h:71-80), so more "
+                "workers do not help; pool construction is inside the sample. `value` above is the "
+                "idealised port (independent shards, no queue) and is the figure the GPU is compared to"},
       "sample": f"{n_cpu} sync lockstep steps of the same {N}-env workload (reset + send/recv) on "
                 f"oracle/dummy_oracle.c, {cores} threads each owning a contiguous env_id shard (no "
                 "barrier between shards); obs:dyn kept lazy (the reference allocates O(N^2) bytes "

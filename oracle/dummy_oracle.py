@@ -52,6 +52,18 @@ def lib():
     L.od_bench_sync_mt.argtypes = [C.c_int32] * 4
     L.od_queue_size.argtypes = [C.c_void_p]
     L.od_is_sync.argtypes = [C.c_void_p]
+    # dummy_pool_mt.c: the reference's queue + worker-thread architecture
+    L.rp_create.restype = C.c_void_p
+    L.rp_create.argtypes = [C.c_int32] * 7
+    L.rp_destroy.argtypes = [C.c_void_p]
+    L.rp_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.rp_send.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rp_recv.argtypes = [C.c_void_p, C.POINTER(_Batch)]
+    L.rp_batch_free.argtypes = [C.POINTER(_Batch)]
+    L.rp_num_threads.argtypes = [C.c_void_p]
+    L.rp_action_check_failed.argtypes = [C.c_void_p]
+    L.rp_bench_sync.restype = C.c_uint64
+    L.rp_bench_sync.argtypes = [C.c_int32] * 4
     _LIB = L
   return _LIB
 
@@ -135,6 +147,79 @@ class DummyOracle:
 
   def bench_sync(self, steps):
     return self._L.od_bench_sync(self._p, steps)
+
+
+def _unpack(b, free, dyn="lazy"):
+  n, m, s = b.num_rows, b.num_player_rows, b.state_num
+  dyn_rows = _arr(b.dyn_rows, m, np.int32)
+  dyn_fill = _arr(b.dyn_fill, m, np.int32)
+  out = [
+    _arr(b.info_env_id, n, np.int32), _arr(b.info_players_env_id, m, np.int32),
+    _arr(b.elapsed_step, n, np.int32), _arr(b.done, n, np.bool_),
+    _arr(b.reward, m, np.float32), _arr(b.discount, m, np.float32),
+    _arr(b.step_type, n, np.int32), _arr(b.trunc, n, np.bool_),
+    _arr(b.obs_raw, m * s, np.int32, (m, s)), (dyn_rows, dyn_fill),
+    _arr(b.players_done, m, np.bool_), _arr(b.players_id, m, np.int32),
+  ]
+  free(C.byref(b))
+  return out
+
+
+class ThreadedDummyOracle:
+  """dummy_pool_mt.c: ActionBufferQueue -> worker threads -> StateBufferQueue, as the reference
+  runs it. `_recv` blocks like the reference's. The arrays of a `_send` are kept alive here until
+  the env's next send (envpool2/core/env.h:106-110 holds the batch the same way)."""
+
+  def __init__(self, num_envs=1, batch_size=0, max_num_players=1, seed=42,
+               max_episode_steps=2**31 - 1, state_num=10, num_threads=0):
+    self._L = lib()
+    self._p = self._L.rp_create(num_envs, batch_size, max_num_players, seed, max_episode_steps,
+                                state_num, num_threads)
+    if not self._p:
+      raise ValueError("invalid oracle config")
+    self.num_envs, self.state_num = num_envs, state_num
+    self._keep = []
+
+  def close(self):
+    if getattr(self, "_p", None):
+      self._L.rp_destroy(self._p)
+      self._p = None
+
+  __del__ = close
+
+  @property
+  def num_threads(self):
+    return self._L.rp_num_threads(self._p)
+
+  @property
+  def action_check_failed(self):
+    return bool(self._L.rp_action_check_failed(self._p))
+
+  def _reset(self, env_ids):
+    ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+    self._L.rp_reset(self._p, ids.ctypes.data, ids.shape[0])
+
+  def _send(self, action):
+    env_id = np.ascontiguousarray(action[0], dtype=np.int32)
+    penv = np.ascontiguousarray(action[1], dtype=np.int32)
+    la = np.ascontiguousarray(action[2], dtype=np.float64)
+    assert la.shape == (env_id.shape[0], 6)
+    self._keep.append((env_id, penv, la))
+    if len(self._keep) > 4 * (self.num_envs + 4):
+      del self._keep[:len(self._keep) // 2]
+    self._L.rp_send(self._p, env_id.shape[0], env_id.ctypes.data, penv.shape[0], penv.ctypes.data,
+                    la.ctypes.data)
+
+  def _recv(self):
+    b = _Batch()
+    self._L.rp_recv(self._p, C.byref(b))
+    return _unpack(b, self._L.rp_batch_free)
+
+
+def bench_sync_threadpool(num_envs, seed, steps, threads):
+  """bench.py's second cpu_baseline figure: the reference's architecture (action queue, worker
+  threads, state-buffer queue with fresh zeroed buffers) at `threads` workers."""
+  return lib().rp_bench_sync(num_envs, seed, steps, threads)
 
 
 def bench_sync_mt(num_envs, seed, steps, threads):

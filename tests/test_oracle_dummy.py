@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle.dummy_oracle import DummyOracle, OracleError
+from oracle.dummy_oracle import DummyOracle, OracleError, ThreadedDummyOracle
 from tests.util import dummy_action
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dummy_survey_traces.json")))
@@ -141,3 +141,82 @@ def test_sharded_oracles_equal_one_pool():
     for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11):
       assert np.array_equal(w[k], np.concatenate([p[k] for p in ps])), (t, k)
     whole._send(dummy_action(ids)); [p._send(dummy_action(ids[4 * r:4 * r + 4])) for r, p in enumerate(parts)]
+
+
+def _same(ra, rb):
+  for k, (x, y) in enumerate(zip(ra, rb)):
+    if isinstance(x, tuple):
+      assert all(np.array_equal(u, v) for u, v in zip(x, y)), k
+    else:
+      assert x.dtype == y.dtype and np.array_equal(x, y), k
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_threaded_architecture_equals_sequential_oracle_sync(threads):
+  """oracle/dummy_pool_mt.c (action queue -> worker threads -> state-buffer queue, the shape of
+  async_envpool.h:116-129) against the sequential restatement: in sync mode `order` fixes every
+  row, so any thread interleaving must give the same batches, partial sends and forced resets
+  included."""
+  n = 600
+  a = DummyOracle(num_envs=n, seed=3)
+  b = ThreadedDummyOracle(num_envs=n, seed=3, num_threads=threads)
+  ids = np.arange(n, dtype=np.int32)
+  a._reset(ids); b._reset(ids)
+  _same(a._recv(), b._recv())
+  rng = np.random.default_rng(threads)
+  for t in range(60):
+    perm = rng.permutation(n).astype(np.int32)[: n if t % 3 else n // 2]
+    if t % 7 == 6:
+      a._reset(perm); b._reset(perm)
+    else:
+      act = dummy_action(perm)
+      a._send(act); b._send(act)
+    _same(a._recv(), b._recv())
+  assert not b.action_check_failed
+  b.close()
+
+
+def test_threaded_architecture_async_rows_by_env():
+  """Async mode: rows arrive in whatever order the workers finish; per env the sequence of rows
+  must be the sequential oracle's."""
+  n, bsz = 64, 16
+  a = DummyOracle(num_envs=n, batch_size=bsz, seed=2)
+  b = ThreadedDummyOracle(num_envs=n, batch_size=bsz, seed=2, num_threads=4)
+  ids = np.arange(n, dtype=np.int32)
+  a._reset(ids); b._reset(ids)
+  seq_a, seq_b = {i: [] for i in range(n)}, {i: [] for i in range(n)}
+  pend_a, pend_b = n, n
+
+  def take(pool, seq):
+    r = pool._recv()
+    for j, e in enumerate(r[0]):
+      seq[int(e)].append((int(r[2][j]), bool(r[3][j]), int(r[6][j]), int(r[8][j, 0]), int(r[8][j, 1])))
+    return r[0]
+
+  for _ in range(40):
+    ea = take(a, seq_a); eb = take(b, seq_b)
+    assert len(ea) == bsz and len(eb) == bsz
+    a._send(dummy_action(ea)); b._send(dummy_action(eb))
+  for _ in range(n // bsz):  # drain what is still in flight
+    take(a, seq_a); take(b, seq_b)
+  for i in range(n):
+    m = min(len(seq_a[i]), len(seq_b[i]))
+    assert m > 0 and seq_a[i][:m] == seq_b[i][:m], i
+  b.close()
+
+
+def test_threaded_architecture_multiplayer_one_worker_is_fifo():
+  """One worker = strictly FIFO = the sequential oracle, ragged player rows included."""
+  n = 9
+  a = DummyOracle(num_envs=n, max_num_players=3, seed=2)
+  b = ThreadedDummyOracle(num_envs=n, max_num_players=3, seed=2, num_threads=1)
+  ids = np.arange(n, dtype=np.int32)
+  a._reset(ids); b._reset(ids)
+  ra, rb = a._recv(), b._recv()
+  _same(ra, rb)
+  for _ in range(12):
+    act = dummy_action(ra[0], players_env_id=ra[1])
+    a._send(act); b._send(act)
+    ra, rb = a._recv(), b._recv()
+    _same(ra, rb)
+  b.close()
