@@ -40,6 +40,60 @@ ALG_ROLLOUT_PER_ENV_LAUNCH = 20
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+class NodeBarrier:
+  """Barrier for the ranks of ONE node: an 8-byte generation counter per rank, each on its own
+  cache line of a shared-memory file; a rank publishes its generation and spins until every
+  rank's has reached it. Set up (file name, creation) over the process group's host backend."""
+
+  def __init__(self, rank, world, dist):
+    import mmap
+    import tempfile
+    import numpy as np
+    self.rank, self.world, self.dist, self.gen = rank, world, dist, 0
+    names = [None]
+    if rank == 0:
+      d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+      fd, path = tempfile.mkstemp(prefix="envpool_amd_bench_", dir=d)
+      os.write(fd, b"\0" * (64 * world))
+      os.close(fd)
+      names[0] = path
+    dist.broadcast_object_list(names, src=0)
+    self.path = names[0]
+    self.f = open(self.path, "r+b")
+    self.mm = mmap.mmap(self.f.fileno(), 64 * world)
+    self.slots = np.frombuffer(self.mm, dtype=np.int64)[::8]
+    self._host_barrier()  # every rank has the file mapped
+    if rank == 0:
+      os.unlink(self.path)
+
+  def _host_barrier(self):
+    import torch
+    self.dist.all_reduce(torch.zeros(1, dtype=torch.int32))  # a CPU tensor: the host backend
+
+  def __call__(self, timeout_s=300.0):
+    self.gen += 1
+    g = self.gen
+    self.slots[self.rank] = g
+    slots = self.slots
+    spins, t0 = 0, None
+    while int(slots.min()) < g:
+      spins += 1
+      if spins & 0xffff == 0:
+        now = time.monotonic()
+        t0 = t0 or now
+        if now - t0 > timeout_s:
+          raise RuntimeError("NodeBarrier: a rank did not arrive")
+
+  def close(self):
+    self._host_barrier()
+    self.slots = None
+    try:
+      self.mm.close()
+    except BufferError:
+      pass
+    self.f.close()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -66,21 +120,33 @@ def main():
 
   # EP_BENCH_REHEARSE=1: run the N>1 code path on a box with ONE GPU (every rank on cuda:0, gloo
   # instead of RCCL, stats gathered through host memory). For checking the logic only.
-  rehearse = os.environ.get("EP_BENCH_REHEARSE") == "1"
+  # EP_BENCH_REHEARSE=2: the same, but with the real process-group set-up (gloo + RCCL): RCCL refuses
+  # two ranks on one GPU, which exercises the fall-back of the stat exchange.
+  rehearse = os.environ.get("EP_BENCH_REHEARSE") in ("1", "2")
+  rehearse_real_init = os.environ.get("EP_BENCH_REHEARSE") == "2"
   dev_index = 0 if rehearse else local_rank
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
+  node_barrier = None
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if rehearse:
-      dist.init_process_group("gloo")
-    else:
-      dist.init_process_group("nccl", device_id=dev)
+    # gloo carries everything that lives on the host (timings, the barrier's set-up); RCCL carries
+    # the one device-side exchange there is, the episode-stat all-gather
+    dist.init_process_group("gloo" if rehearse and not rehearse_real_init else "cpu:gloo,cuda:nccl")
+    node_barrier = NodeBarrier(rank, world, dist)
 
   def barrier():
-    if world > 1:
-      dist.barrier()
+    # "barrier + torch.cuda.synchronize()" of the bench contract. All ranks are on ONE node by that
+    # contract, so the barrier is a generation counter per rank in a shared-memory file (about a
+    # microsecond); an RCCL or gloo barrier costs more than the 20-step region (47 us) it brackets.
+    # EP_BENCH_BARRIER=dist restores dist.barrier(). Device first, then ranks: when the barrier
+    # falls, every rank's GPU is idle (opening side) / has finished its K steps (closing side).
     torch.cuda.synchronize()
+    if world > 1:
+      if os.environ.get("EP_BENCH_BARRIER") == "dist":
+        dist.barrier()
+      else:
+        node_barrier()
 
   L = capi.lib()
   N, T = NUM_ENVS, T_FUSED
@@ -116,21 +182,54 @@ def main():
   def recv_n(n):
     check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, n, batches))
 
-  def exchange_stats():
-    if world > 1:
-      check(L.ep_pool_episode_stats_async(h, st_ret.data_ptr(), st_len.data_ptr(), None,
-                                          torch.cuda.current_stream().cuda_stream))
-      if rehearse:
-        torch.cuda.current_stream().synchronize()
+  # BASELINE config 4 / SURVEY.md 8(d): "every K=64 steps RCCL all-gather of (return, length) per
+  # rank on a side stream". The pool snapshots its statistics on its own stream; the side stream
+  # waits for that snapshot and runs the all-gather; the host waits for neither.
+  STATS_EVERY = 64
+  exch = {"since": 0, "count": 0,
+          "via": "host+gloo (rehearsal)" if rehearse and not rehearse_real_init else "RCCL all_gather_into_tensor",
+          "in_run": 0}
+  side = torch.cuda.Stream(device=dev) if world > 1 else None
+
+  def exchange_stats_now():
+    with torch.cuda.stream(side):
+      check(L.ep_pool_episode_stats_async(h, st_ret.data_ptr(), st_len.data_ptr(), None, side.cuda_stream))
+      if exch["via"].startswith("RCCL"):
+        dist.all_gather_into_tensor(g_ret, st_ret)
+        dist.all_gather_into_tensor(g_len, st_len)
+      else:
+        side.synchronize()
         parts = [torch.zeros(N, dtype=torch.float32) for _ in range(world)]
         dist.all_gather(parts, st_ret.cpu())
         g_ret.copy_(torch.cat(parts))
         parts = [torch.zeros(N, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(parts, st_len.cpu())
         g_len.copy_(torch.cat(parts))
-      else:
-        dist.all_gather_into_tensor(g_ret, st_ret)
-        dist.all_gather_into_tensor(g_len, st_len)
+    exch["count"] += 1
+    exch["in_run"] += 1
+
+  def exchange_stats(steps_done):
+    if world > 1:
+      exch["since"] += steps_done
+      if exch["since"] >= STATS_EVERY:
+        exch["since"] = 0
+        exchange_stats_now()
+
+  if world > 1:
+    # first exchange, untimed: RCCL connects here. Should it fail on this machine, the gather falls
+    # back to host memory + gloo on every rank alike and the line says so.
+    failed = 0
+    try:
+      exchange_stats_now()
+      torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001
+      failed = 1
+      print(f"[bench] rank {rank}: RCCL all-gather failed ({ex!r}); using host + gloo", file=sys.stderr, flush=True)
+    flag = torch.tensor([failed], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) and exch["via"].startswith("RCCL"):
+      exch["via"] = "host+gloo (RCCL all-gather failed on this machine)"
+      exchange_stats_now()
 
   breakdown = os.environ.get("EP_BENCH_BREAKDOWN") == "1"
   phases = {}
@@ -144,10 +243,10 @@ def main():
     for i in range(1, len(chunks)):
       check(L.ep_pool_rollout(h, chunks[i], 5, ptrs, dims, strides))  # next rollout queued ...
       recv_n(chunks[i - 1])                                           # ... while this one is received
-      exchange_stats()
+      exchange_stats(chunks[i - 1])
     recv_n(chunks[-1])
     p2 = time.perf_counter()
-    exchange_stats()
+    exchange_stats(chunks[-1])
     check(L.ep_pool_sync(h))
     if breakdown:
       phases.update(first_rollout_call_us=(p1 - p0) * 1e6, until_last_recv_us=(p2 - p1) * 1e6,
@@ -181,11 +280,12 @@ def main():
   R = max(1, args.repeats)
   # The K-step region, R times; each run is bracketed by barrier + synchronize on both sides and
   # times exactly K lockstep steps. The line reports the MEDIAN run (max over ranks per run).
-  walls, kern = [], []
+  walls, kern, exch_in_run = [], [], []
   REHEARSALS = 4  # untimed runs of the same region first: the pool creates its timing events in them
   for r in range(-REHEARSALS, R):
     check(L.ep_pool_set_timing(h, 1))
     check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
+    exch["in_run"] = 0
     barrier()
     t0 = time.perf_counter()
     run_fused(K)
@@ -196,12 +296,13 @@ def main():
     if r < 0:
       continue
     walls.append(t1 - t0)
+    exch_in_run.append(exch["in_run"])
     kern.append((tot.value, max(1, cnt.value)))
     if breakdown and rank == 0:
       print(f"[breakdown] run {r}: wall {1e6 * (t1 - t0):.1f} us, kernel {tot.value:.1f} us in {cnt.value} launches, "
             + ", ".join(f"{k} {v:.1f}" for k, v in phases.items()), file=sys.stderr, flush=True)
   if world > 1:
-    tmax = torch.tensor(walls, dtype=torch.float64, device="cpu" if rehearse else dev)
+    tmax = torch.tensor(walls, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     walls = [float(x) for x in tmax.tolist()]
   order = sorted(range(R), key=lambda i: walls[i])
@@ -430,10 +531,10 @@ def main():
     try:
       from tools import bench_ygo
       r = bench_ygo.run_shard(dev_index, barrier)
-      tm = torch.tensor([r["large_wall_s"], r["pipeline_wall_s"]], dtype=torch.float64, device="cpu" if rehearse else dev)
+      tm = torch.tensor([r["large_wall_s"], r["pipeline_wall_s"]], dtype=torch.float64)
       dist.all_reduce(tm, op=dist.ReduceOp.MAX)
       ring = torch.tensor([r["ring_4_threads"]["batches_per_s"], r["ring_4_threads"]["gpu_time_hidden_behind_emission"] or 0.0],
-                          dtype=torch.float64, device="cpu" if rehearse else dev)
+                          dtype=torch.float64)
       dist.all_reduce(ring, op=dist.ReduceOp.SUM)
       if rank == 0:
         ygo = {
@@ -472,13 +573,17 @@ def main():
       "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
       "repeats": R, "clock_warm_launches": CLOCK_WARM_LAUNCHES, "untimed_rehearsals": REHEARSALS,
       "ms_per_step_all_runs": [w / K * 1e3 for w in walls],
+      **({"stats_exchanges_in_each_run": exch_in_run, "stats_exchanges_in_median_run": exch_in_run[med],
+          "stats_exchanges_total": exch["count"],
+          "barrier": os.environ.get("EP_BENCH_BARRIER", "shared-memory generation barrier (one node)")} if world > 1 else {}),
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
       "data": "synthetic",
       "config": {
         "workload": f"Dummy-v0 num_envs={N} per GPU, seed={SEED}, sync lockstep reset/step, "
                     f"fused rollout T={T} steps/launch, device-resident actions, StateBuffer ring depth {2 * T}",
         "global_num_envs": world * N, "sharding": "env_id blocks, one independent pool per GPU",
-        "collective": "RCCL all-gather of episode (return,length) per rollout" if world > 1 else "none",
+        "collective": (f"all-gather of episode (return,length), {N * 8} B per rank, every {STATS_EVERY} steps on a side "
+                       f"stream, via {exch['via']}") if world > 1 else "none",
       },
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -496,6 +601,7 @@ def main():
 
   pool.close()
   if world > 1:
+    node_barrier.close()
     dist.destroy_process_group()
 
 

@@ -230,6 +230,38 @@ def test_sharded_stats_all_gather_gloo_world2(tmp_path):
   assert out.stdout.count("ok") == 2
 
 
+_BARRIER_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["EP_ROOT"])
+import torch.distributed as dist
+from bench import NodeBarrier
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+b = NodeBarrier(rank, world, dist)
+assert not os.path.exists(b.path)            # unlinked once every rank has it mapped
+for i in range(300):
+  if i % world == rank and i % 10 == 0:
+    time.sleep(0.002)                        # a straggler: nobody may pass generation i+1 before it arrives
+  b()
+  assert int(b.slots.min()) >= i + 1, (i, b.slots)
+  assert int(b.slots.max()) <= i + 2, (i, b.slots)   # and nobody can be more than one barrier ahead
+b.close(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_bench_node_barrier_gloo_world2(tmp_path):
+  """bench.py's shared-memory barrier (the N>1 timed region is bracketed by it)."""
+  script = tmp_path / "worker.py"
+  script.write_text(_BARRIER_WORKER)
+  env = dict(os.environ, EP_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+  out = subprocess.run(
+    [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+     "--master-port", "29537", str(script)], env=env, capture_output=True, text=True, timeout=240)
+  assert out.returncode == 0, out.stdout + out.stderr
+  assert out.stdout.count("ok") == 2
+
+
 def test_ygopro_spec_surface():
   """ygopro.h:1177-1207 + env_spec.h:25-42: keys, defaults, dtypes, shapes, bounds."""
   import envpool_amd
