@@ -41,8 +41,24 @@ synth: tools/libygosynth.so
 tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpool_amd.h
 	gcc -O2 -fPIC -shared -std=gnu11 -Wall -pthread -o $@ $<
 
+# Host-code sanitizer target (GPU sanitizers are not available on this pool): the library's host
+# code under ASan + UBSan, driven by tools/sanitize_host.cpp on the CPU. Not part of `all`.
+CLANG ?= /opt/rocm/lib/llvm/bin/clang
+SANFLAGS := -fsanitize=address -fsanitize=undefined -fno-omit-frame-pointer
+sanitize: build/sanitize_host
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 build/sanitize_host
+
+build/sanitize_host: tools/sanitize_host.cpp tools/ygo_synth.c $(HIP_SRCS) $(HIP_DEPS)
+	mkdir -p build
+	$(CLANG) -O1 -g -std=gnu11 -pthread $(SANFLAGS) -c -o build/ygo_synth_san.o tools/ygo_synth.c
+	$(CLANG)++ -O1 -g -std=c++17 $(SANFLAGS) -c -o build/sanitize_host.o tools/sanitize_host.cpp
+	for f in $(HIP_SRCS); do $(HIPCC) --offload-arch=$(ARCH) -O1 -g -std=c++17 -fPIC -Iinclude \
+	  $(foreach f,$(SANFLAGS),-Xarch_host $(f)) -c -o build/san_$$(basename $$f .hip).o $$f || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) $(SANFLAGS) -o $@ build/sanitize_host.o \
+	  $(patsubst $(CSRC)/%.hip,build/san_%.o,$(HIP_SRCS)) build/ygo_synth_san.o -pthread
+
 clean:
 	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib pymod oracle synth clean
+.PHONY: all lib pymod oracle synth sanitize clean
