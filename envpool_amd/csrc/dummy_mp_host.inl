@@ -5,9 +5,11 @@ namespace epk_mp {
 
 // Fills and launches mp_step_fused for `cnt` items. `sc` / `ticket_base` / epochs: see
 // dummy_mp_kernels.hpp. Shared by the pool path and ep_dummy_send_noalloc.
-int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt) {
+int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count) {
   a.n = cnt;
   a.num_tiles = (cnt + epk::kMpTile - 1) / epk::kMpTile;
+  // a CU holds 8 workgroups of 256 threads; half of that is the bound for "all tiles at once"
+  a.static_tiles = (a.num_tiles <= 4 * cu_count && !getenv("EP_MP_FORCE_TICKET")) ? 1 : 0;  // (the variable: tests of the ticket path)
   hipLaunchKernelGGL(epk::mp_step_fused, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
@@ -17,8 +19,12 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
                int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked) {
   const uint64_t B = (uint64_t)p->B;
   // one histogram per send (ParseAction scans the WHOLE players.env_id array for every env,
-  // env.h:128-132); its epoch is the stamp of the send's first launch
-  const uint32_t count_epoch = next_stamp(p);
+  // env.h:128-132), tagged with a per-pool send counter
+  uint32_t count_epoch = (uint32_t)++p->mp_count_epoch;
+  if (count_epoch == 0) {  // 2^32 sends: tags of the last lap must not look new again
+    HIP_TRY(hipMemsetAsync(p->mp_sc.counts, 0, 8 * (size_t)p->N, p->stream));
+    count_epoch = (uint32_t)++p->mp_count_epoch;
+  }
   if (!force_reset && np_rows > 0) {
     hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, p->stream, d_penv,
                        np_rows, p->cfg.env_id_offset, p->N, p->mp_sc.counts, count_epoch);
@@ -62,9 +68,9 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     a.first_segment = sh.alloc_count == 0 ? 1 : 0;
     {
       TimedScope ts(p);
-      if (int rc = launch_fused(p->stream, a, cnt)) return rc;
+      if (int rc = launch_fused(p->stream, a, cnt, p->cu_count)) return rc;
     }
-    p->mp_ticket_total += (uint32_t)a.num_tiles;
+    if (!a.static_tiles) p->mp_ticket_total += (uint32_t)a.num_tiles;
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);

@@ -9,12 +9,15 @@
 //
 // Two launches per send:
 //   mp_count_rows   players.env_id histogram (how many action rows each env owns, env.h:128-132)
-//                   into epoch-tagged 64-bit counters, so nothing has to be cleared afterwards;
+//                   into epoch-tagged 64-bit counters, so nothing has to be cleared between sends;
 //   mp_step_fused   256 items per workgroup: env step + shared-row keys, a workgroup scan of
-//                   num_players, a single-pass decoupled look-back across workgroups (tile ids
-//                   from a ticket, so a tile only ever waits for tiles that already run), then
-//                   the workgroup writes its contiguous block of player rows cooperatively
-//                   (coalesced 4-byte stores per key, 16-byte stores for obs:raw). The last tile
+//                   num_players, a single-pass decoupled look-back across workgroups (256 tiles
+//                   per hop; tile ids are blockIdx when the whole launch fits on the device at
+//                   once - every tile a tile waits for is then resident or will be without anyone
+//                   else finishing first - and come from a ticket otherwise, so that a tile only
+//                   ever waits for tiles that already run; the ticket costs ~3 us at 256 tiles), then
+//                   the workgroup writes its contiguous block of player rows, one thread per row
+//                   (one owner search per row, 16- and 8-byte stores for the obs:raw row). The last tile
 //                   leaves the slot's player total in a host-mapped word: recv needs no copy.
 // The scratch (counters, look-back granules, ticket) comes in as an argument: a pool brings its
 // own allocation, ep_dummy_send_noalloc the library's static array.
@@ -46,14 +49,13 @@ __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int
   if (j >= np_rows) return;
   int32_t local = penv[j] - env_off;
   if (local < 0 || local >= N) return;  // rows of envs this pool does not own match nothing
+  // two single-shot atomics, no retry loop: the max moves a counter of an older send to
+  // {epoch, 0} and leaves one of this send alone; then the row is added. Epochs only grow between
+  // clears of the array (the host clears it when its 32-bit epoch wraps), and any number of rows
+  // may name the same env without the threads starving each other.
   unsigned long long* c = counts + local;
-  unsigned long long old = __hip_atomic_load(c, EP_RLX_AGENT), assumed;
-  do {
-    assumed = old;
-    const unsigned long long fresh = ((unsigned long long)epoch << 32) | 1ull;
-    const unsigned long long next = (uint32_t)(assumed >> 32) == epoch ? assumed + 1ull : fresh;
-    old = atomicCAS(c, assumed, next);
-  } while (old != assumed);
+  atomicMax(c, (unsigned long long)epoch << 32);
+  atomicAdd(c, 1ull);
 }
 
 struct MpFusedArgs {
@@ -74,6 +76,7 @@ struct MpFusedArgs {
   uint32_t* slot_players;  // device: player rows in the slot so far (read by tile 0 unless first_segment, written by the last tile)
   uint32_t* host_players;  // host-visible copy written by the last tile (may be null)
   int32_t n, row0, force_reset, P, first_segment, num_tiles;
+  int32_t static_tiles;  // tile id = blockIdx.x (every tile of the launch fits on the device at once)
 };
 
 __device__ __forceinline__ int mp_find_item(const int32_t* excl, int r) {
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   __shared__ int32_t s_wave_tot[kMpTile / 64];
   __shared__ uint32_t s_tile, s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd(a.sc.ticket, 1u) - a.ticket_base;
+  if (tid == 0) s_tile = a.static_tiles ? blockIdx.x : atomicAdd(a.sc.ticket, 1u) - a.ticket_base;
   __syncthreads();
   const int tile = (int)s_tile;
   const int64_t i = (int64_t)tile * kMpTile + tid;
@@ -189,14 +192,33 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
       int look = tile - 1;  // nearest tile not accounted for yet
       unsigned spins = 0;
       for (;;) {
-        const int t = look - lane;
-        uint32_t flag = 0, val = 0;
-        if (t >= 0) {
-          const unsigned long long g = __hip_atomic_load(tiles + t, EP_RLX_AGENT);
-          if ((uint32_t)(g >> 32) == a.tile_epoch) { flag = (uint32_t)(g >> 30) & 3u; val = (uint32_t)g & kMpValueMask; }
+        // one hop covers the 256 nearest tiles: lane l looks at tiles look-4l .. look-4l-3 (four
+        // independent loads), walks them nearest first and stops at the first inclusive value
+        // (state 1) or at the first tile that has not published yet (state 2)
+        unsigned long long g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = look - 4 * lane - q;
+          g[q] = t >= 0 ? __hip_atomic_load(tiles + t, EP_RLX_AGENT) : 0ull;
         }
-        const unsigned long long m_incl = __ballot(t >= 0 && flag == kMpFlagIncl);
-        const unsigned long long m_wait = __ballot(t >= 0 && flag == 0u);
+        uint32_t part = 0;
+        int state = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = look - 4 * lane - q;
+          if (state == 0 && t >= 0) {
+            const bool fresh = (uint32_t)(g[q] >> 32) == a.tile_epoch;
+            const uint32_t flag = fresh ? (uint32_t)(g[q] >> 30) & 3u : 0u;
+            if (flag == 0u) {
+              state = 2;
+            } else {
+              part += (uint32_t)g[q] & kMpValueMask;
+              if (flag == kMpFlagIncl) state = 1;
+            }
+          }
+        }
+        const unsigned long long m_incl = __ballot(state == 1);
+        const unsigned long long m_wait = __ballot(state == 2);
         const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
         const int first_wait = m_wait ? __builtin_ctzll(m_wait) : 64;
         if (first_wait < first_incl) {  // a tile in front of the nearest inclusive one has not published yet
@@ -204,15 +226,15 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
             if (lane == 0) a.err->env_id_range = 1u;
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
           continue;
         }
-        uint32_t part = (t >= 0 && lane <= first_incl) ? val : 0u;
+        if (lane > first_incl) part = 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
         base += part;
-        if (first_incl < 64 || look < 64) break;
-        look -= 64;
+        if (first_incl < 64 || look < 256) break;
+        look -= 256;
       }
       if (lane == 0)
         __hip_atomic_store(tiles + tile, tag | ((unsigned long long)kMpFlagIncl << 30) | (base + (uint32_t)total), EP_RLX_AGENT);
@@ -229,7 +251,8 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   if (tile >= a.num_tiles) return;
   const int64_t R0 = (int64_t)s_base;
 
-  // ---- player rows: the tile's `total` rows are contiguous from R0 ---------------------------
+  // ---- player rows: the tile's `total` rows are contiguous from R0; one thread per row -----------
+  const int S = a.pc.S;
   for (int r = tid; r < total; r += kMpTile) {
     const int j = mp_find_item(s_excl, r);
     const int k = r - s_excl[j];
@@ -240,28 +263,30 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
     a.slot.pdone[R] = done;                                  // :149/:201
     a.slot.reward[R] = (float)(-k);                          // :152/:204
     a.slot.discount[R] = (k == 0 && !done) ? 1.f : 0.f;      // env.h:202 hits element 0 only
+    // obs:raw row {state, raw1, 0, ...} (:150-151/:202-203; the rest stays at the buffer's zero)
+    int32_t* const row = a.slot.raw + R * S;
+    const int32_t v0 = s_state[j], v1 = s_raw1[j];
+    if (S == 10) {
+      // 40-byte rows from a 16-byte aligned base: even rows start on 16 bytes, odd rows 8 past
+      if ((R & 1) == 0) {
+        *reinterpret_cast<int4*>(row) = make_int4(v0, v1, 0, 0);
+        *reinterpret_cast<int4*>(row + 4) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int2*>(row + 8) = make_int2(0, 0);
+      } else {
+        *reinterpret_cast<int2*>(row) = make_int2(v0, v1);
+        *reinterpret_cast<int4*>(row + 2) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4*>(row + 6) = make_int4(0, 0, 0, 0);
+      }
+    } else if ((S & 1) == 0) {
+      int2* const row2 = reinterpret_cast<int2*>(row);
+      row2[0] = make_int2(v0, v1);
+      for (int c = 1; c < (S >> 1); ++c) row2[c] = make_int2(0, 0);
+    } else {
+      row[0] = v0;
+      row[1] = v1;
+      for (int c = 2; c < S; ++c) row[c] = 0;
+    }
   }
-  // obs:raw rows {state, raw1, 0, ...}: scalar stores up to the first 16-byte boundary, 16-byte
-  // stores in the middle
-  const int S = a.pc.S;
-  const int64_t E0 = R0 * S;
-  const int nelem = total * S;
-  int32_t* const raw = a.slot.raw + E0;
-  auto value = [&](int e) -> int32_t {
-    const int r = e / S, c = e - r * S;
-    if (c >= 2) return 0;
-    const int j = mp_find_item(s_excl, r);
-    return c == 0 ? s_state[j] : s_raw1[j];
-  };
-  const int lead = min(nelem, (int)((4 - (E0 & 3)) & 3));
-  if (tid < lead) raw[tid] = value(tid);
-  const int nvec = (nelem - lead) >> 2;
-  for (int q = tid; q < nvec; q += kMpTile) {
-    const int e = lead + (q << 2);
-    *reinterpret_cast<int4*>(raw + e) = make_int4(value(e), value(e + 1), value(e + 2), value(e + 3));
-  }
-  const int tail0 = lead + (nvec << 2);
-  if (tid < nelem - tail0) raw[tail0 + tid] = value(tail0 + tid);
 }
 
 }  // namespace epk

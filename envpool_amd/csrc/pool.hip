@@ -74,6 +74,7 @@ struct ep_pool {
   // multi-player scratch (dummy_mp_kernels.hpp)
   epk::MpScratch mp_sc{};              // histogram counters [N], look-back granules, ticket
   uint32_t mp_ticket_total = 0;        // tiles launched so far (the ticket counter never goes back)
+  uint64_t mp_count_epoch = 0;         // sends so far: low 32 bits tag the row histogram of a send
   uint32_t* d_slot_players = nullptr;  // [Q] player_offset of each slot (device running total)
   uint32_t* h_slot_players = nullptr;  // [EQ] host-mapped: final player_offset per batch generation
   uint32_t* d_host_players = nullptr;  // device alias of h_slot_players
@@ -1465,6 +1466,7 @@ namespace {
 constexpr int kNoallocMaxDevices = 64;
 std::mutex g_noalloc_mu;
 unsigned char* g_noalloc_ptr[kNoallocMaxDevices];  // per device: where ITS copy of `scratch` lives
+int g_noalloc_cus[kNoallocMaxDevices];             // per device: compute units
 }  // namespace
 
 extern "C" {
@@ -1506,15 +1508,18 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   if (cfg->device_id < 0 || cfg->device_id >= kNoallocMaxDevices) return fail(EP_ERR_INVALID, "device_id %d out of range", cfg->device_id);
   HIP_TRY(hipSetDevice(cfg->device_id));
   unsigned char* sc = nullptr;
+  int cus = 0;
   {
     std::lock_guard<std::mutex> lk(g_noalloc_mu);
     if (!g_noalloc_ptr[cfg->device_id]) {  // set-up, once per device, with that device current
       unsigned char* ptr = nullptr;
       HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
       if (!ptr) return fail(EP_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+      HIP_TRY(hipDeviceGetAttribute(&g_noalloc_cus[cfg->device_id], hipDeviceAttributeMultiprocessorCount, cfg->device_id));
       g_noalloc_ptr[cfg->device_id] = ptr;
     }
     sc = g_noalloc_ptr[cfg->device_id];
+    cus = g_noalloc_cus[cfg->device_id];
   }
   hipStream_t st = (hipStream_t)stream;
   // what must start at zero: the result words, the ticket and (multi-player steps) the histogram
@@ -1568,7 +1573,7 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   a.force_reset = force_reset ? 1 : 0;
   a.P = P;
   a.first_segment = 1;
-  return epk_mp::launch_fused(st, a, n);
+  return epk_mp::launch_fused(st, a, n, cus);
 }
 
 int32_t ep_pool_num_envs(ep_pool* p) { return p ? p->N : 0; }

@@ -265,6 +265,33 @@ def test_multiplayer_ragged_player_dim(P, n, B):
     outstanding += sel.size
 
 
+def test_multiplayer_ticket_tile_ids(monkeypatch):
+  """The look-back scan with tile ids from the ticket counter (what a launch too large for the
+  device takes) gives the same rows as with static tile ids."""
+  monkeypatch.setenv("EP_MP_FORCE_TICKET", "1")
+  test_multiplayer_ragged_player_dim(3, 3000, 0)
+  test_multiplayer_ragged_player_dim(4, 1500, 500)
+
+
+def test_multiplayer_all_rows_name_one_env():
+  """Every players.env_id row names the same env: that env's action_num is the whole row count
+  (env.h:128-132), everyone else's 0 - and the row histogram must not crawl on one counter."""
+  n, P = 4096, 3
+  g, o = _pair(num_envs=n, max_num_players=P, seed=5)
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  assert_batches_equal(g._recv(), o._recv(), "reset")
+  import time
+  for t, target in enumerate((7, 0, n - 1)):
+    pe = np.full(2 * n, target, dtype=np.int32)
+    a = dummy_action(ids, players_env_id=pe)
+    t0 = time.perf_counter()
+    g._send(a); gr = g._recv()
+    assert time.perf_counter() - t0 < 2.0
+    o._send(a)
+    assert_batches_equal(gr, o._recv(), f"t={t}")
+
+
 def test_checkpoint_roundtrip():
   import ctypes as C
   from envpool_amd import capi
