@@ -54,7 +54,19 @@ SYMBOLS = [
   "ep_ygo_async_begin", "ep_ygo_alloc_record", "ep_ygo_record_done", "ep_ygo_recv", "ep_ygo_set_recv_timeout",
   "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
   "ep_ygo_commit_slot_packed", "ep_ygo_emit_records_packed",
+  "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
+  "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads",
 ]
+
+# the duel-engine callbacks of ep_ygo_pool_create
+ENGINE_RESET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(RawState))
+ENGINE_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(RawState))
+
+
+class Engine(C.Structure):
+  """ep_ygo_engine. `reset` / `step` may be addresses of native functions (C.cast(fn, c_void_p).value)
+  or ENGINE_*_FN objects wrapping Python callables (keep those alive as long as the pool)."""
+  _fields_ = [("ctx", C.c_void_p), ("reset", C.c_void_p), ("step", C.c_void_p)]
 
 _bound = None
 
@@ -98,6 +110,16 @@ def lib():
     L.ep_ygo_commit_slot_packed.argtypes = [vp, i32, vp, i64]
     L.ep_ygo_emit_records_packed.argtypes = [vp, C.POINTER(RawState), i32, vp]
     L.ep_ygo_ring_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ep_ygo_pool_create.argtypes = [C.POINTER(YgoConfig), C.POINTER(Engine), i32, i32, i32, i32, C.POINTER(CardData), i32,
+                                     C.POINTER(vp)]
+    L.ep_ygo_pool_destroy.argtypes = [vp]
+    L.ep_ygo_pool_send.argtypes = [vp, i32, vp, vp]
+    L.ep_ygo_pool_reset.argtypes = [vp, i32, vp]
+    L.ep_ygo_pool_recv.argtypes = [vp, i32, C.POINTER(capi.Batch)]
+    L.ep_ygo_pool_set_recv_timeout.argtypes = [vp, i64]
+    L.ep_ygo_pool_encoder.argtypes = [vp]
+    L.ep_ygo_pool_encoder.restype = vp
+    L.ep_ygo_pool_num_threads.argtypes = [vp]
     L.ep_ygo_history_push.argtypes = [C.POINTER(YgoConfig), vp, C.POINTER(i32), i32, C.c_char_p, vp, i32]
     _bound = L
   return _bound
@@ -159,6 +181,75 @@ class YgoEncoderC:
   def collect(self, allow=()):
     b = capi.Batch()
     rc = capi._check(self._L.ep_ygo_collect(self._h, capi.EP_MEM_HOST, C.byref(b)), allow=allow)
+    out = capi.batch_to_numpy(b)
+    self._L.ep_batch_release(C.byref(b))
+    self.last_status = rc
+    return out
+
+
+def make_engine(ctx, reset, step):
+  """Engine struct from native function addresses (ints) or Python callables
+  `reset(ctx, env_id, state_ptr) -> int`, `step(ctx, env_id, action, state_ptr) -> int`.
+  Returns (Engine, keepalive): hold `keepalive` as long as the pool lives."""
+  keep = []
+
+  def addr(f, proto):
+    if isinstance(f, int):
+      return f
+    cb = f if isinstance(f, proto) else proto(f)
+    keep.append(cb)
+    return C.cast(cb, C.c_void_p).value
+  return Engine(ctx, addr(reset, ENGINE_RESET_FN), addr(step, ENGINE_STEP_FN)), keep
+
+
+class YgoPoolC:
+  """ep_ygo_pool: AsyncEnvPool<YGOProEnv> with the duel engine behind callbacks."""
+
+  def __init__(self, cfg, engine, num_envs, batch_size, table, n_table, num_threads=0, thread_affinity_offset=-1):
+    self._L = lib()
+    self.cfg = cfg
+    self._engine = engine  # (the struct is copied by the library; the callbacks it names must stay alive)
+    h = C.c_void_p()
+    capi._check(self._L.ep_ygo_pool_create(C.byref(cfg), C.byref(engine), num_envs, batch_size, num_threads,
+                                           thread_affinity_offset, table, n_table, C.byref(h)))
+    self._h = h
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._L.ep_ygo_pool_destroy(self._h)
+      self._h = None
+
+  __del__ = close
+
+  @property
+  def handle(self):
+    return self._h
+
+  @property
+  def encoder_handle(self):
+    return C.c_void_p(self._L.ep_ygo_pool_encoder(self._h))
+
+  @property
+  def num_threads(self):
+    return self._L.ep_ygo_pool_num_threads(self._h)
+
+  def set_recv_timeout(self, ms):
+    capi._check(self._L.ep_ygo_pool_set_recv_timeout(self._h, ms))
+
+  def send(self, env_id, action):
+    env_id = np.ascontiguousarray(env_id, dtype=np.int32)
+    action = np.ascontiguousarray(action, dtype=np.int32)
+    if action.shape != env_id.shape:
+      raise ValueError(f"action has shape {action.shape}, env_id {env_id.shape}")
+    capi._check(self._L.ep_ygo_pool_send(self._h, env_id.shape[0], env_id.ctypes.data, action.ctypes.data))
+
+  def reset(self, env_id):
+    env_id = np.ascontiguousarray(env_id, dtype=np.int32)
+    capi._check(self._L.ep_ygo_pool_reset(self._h, env_id.shape[0], env_id.ctypes.data))
+
+  def recv(self, allow=()):
+    b = capi.Batch()
+    rc = capi._check(self._L.ep_ygo_pool_recv(self._h, capi.EP_MEM_HOST, C.byref(b)), allow=allow)
     out = capi.batch_to_numpy(b)
     self._L.ep_batch_release(C.byref(b))
     self.last_status = rc

@@ -8,6 +8,7 @@ this library, so there is no `_YGOProEnvPool` that can run duels: what replaces 
 `WriteState` is `YGOProEncoder`, which takes the host engine's per-env state (reference forms or
 packed records) and returns the batch in `_state_keys` order, encoded on the GPU.
 """
+import ctypes as C
 from typing import Any, Dict, List, Sequence, Tuple
 
 import numpy as np
@@ -135,19 +136,81 @@ class YGOProEncoder:
     return d
 
 
-def _no_engine(*_a, **_k):
-  raise RuntimeError(
-    "YGOPro-v0: the duel engine (ygopro-core, Lua, SQLite card database) is not part of envpool_amd; "
-    "run the engine on host threads and encode its states with envpool_amd.ygopro.YGOProEncoder")
+_MODULE = {"engine_factory": None, "card_table": None, "device_id": 0}
 
 
-class YGOProRawEnvPool:
-  """Placeholder so that `make("YGOPro-v0", ...)` explains itself instead of failing obscurely."""
+def init_module(engine_factory, card_table, device_id: int = 0) -> None:
+  """Counterpart of the reference's `init_module(db_path, code_list_file, decks)`
+  (envpool2/ygopro/ygopro.h:1030-1064, called once before any pool is made): tells this package
+  where the duel engine and the card data come from, since neither is part of envpool_amd.
 
-  def __init__(self, *a, **k):
-    _no_engine()
+  `engine_factory(spec) -> (ctx, reset, step[, owner])`: `ctx` an integer / pointer handed back to
+  the callbacks; `reset` / `step` addresses of native functions with the `ep_ygo_engine` signatures
+  (include/envpool_amd_ygo.h) or Python callables (those hold the GIL: fine for tests, not for
+  throughput); `owner` anything that must stay alive as long as the pool.
+  `card_table`: sequence of (code, type, level, attribute, race, attack, defense, card_id) or a
+  ctypes array of `capi_ygo.CardData` — `cards_` / `card_ids_` after the reference's init_module."""
+  _MODULE.update(engine_factory=engine_factory, card_table=card_table, device_id=device_id)
 
 
-YGOProDMEnvPool = YGOProGymEnvPool = YGOProGymnasiumEnvPool = YGOProRawEnvPool
+class _YGOProEnvPool:
+  """The raw boundary of the reference's pybind `_YGOProEnvPool` (py_envpool.h:279-287): `_spec`,
+  `_state_keys`, `_action_keys`, `_send(list)`, `_recv() -> list`, `_reset(env_ids)`, over
+  `ep_ygo_pool` (envpool_amd/csrc/ygo_pool.hip). `_recv` returns the 16 arrays of `_state_keys`;
+  the additive `aux:h_card_ids` of the last batch is kept in `last_h_card_ids`."""
 
-__all__ = ["YGOProEnvSpec", "YGOProEncoder", "CONFIG_KEYS", "DEFAULT_CONFIG_VALUES", "STATE_KEYS", "ACTION_KEYS"]
+  _state_keys = STATE_KEYS
+  _action_keys = ACTION_KEYS
+
+  def __init__(self, spec: _YGOProEnvSpec):
+    if _MODULE["engine_factory"] is None:
+      raise RuntimeError(
+        "YGOPro-v0: the duel engine (ygopro-core, Lua, SQLite card database) is not part of envpool_amd; "
+        "call envpool_amd.ygopro.init_module(engine_factory, card_table) first (the reference's init_module "
+        "plays the same role), or encode states of your own engine with envpool_amd.ygopro.YGOProEncoder")
+    from .. import capi_ygo
+    self._spec = spec
+    c = dict(zip(CONFIG_KEYS, spec._config_values))
+    made = tuple(_MODULE["engine_factory"](spec))
+    ctx, reset, step = made[:3]
+    self._owner = made[3:] or None
+    engine, self._keep = capi_ygo.make_engine(ctx, reset, step)
+    table = _MODULE["card_table"]
+    if not isinstance(table, C.Array):
+      rows = list(table)
+      tab = (capi_ygo.CardData * max(1, len(rows)))()
+      for i, r in enumerate(rows):
+        tab[i] = capi_ygo.CardData(*[int(v) for v in r], 0)
+      table = tab
+    cfg = capi_ygo.default_config(
+      max_cards=c["max_cards"], max_options=c["max_options"], n_history_actions=c["n_history_actions"],
+      max_multi_select=c["max_multi_select"], max_episode_steps=c["max_episode_steps"],
+      device_id=_MODULE["device_id"], ring_depth=0, max_batch=c["batch_size"])
+    self._pool = capi_ygo.YgoPoolC(cfg, engine, c["num_envs"], c["batch_size"], table, len(table),
+                                   num_threads=c["num_threads"], thread_affinity_offset=c["thread_affinity_offset"])
+    self.last_h_card_ids = None
+
+  def close(self) -> None:
+    self._pool.close()
+
+  def _send(self, action: List[np.ndarray]) -> None:
+    # _action_keys order: env_id, players.env_id, action (env_spec.h:31-35, ygopro.h:1203-1207)
+    self._pool.send(action[0], action[2])
+
+  def _reset(self, env_ids: np.ndarray) -> None:
+    self._pool.reset(env_ids)
+
+  def _recv(self) -> List[np.ndarray]:
+    from .. import capi
+    out = self._pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+    self.last_h_card_ids = out[16]
+    return out[:16]
+
+
+from ..python.api import py_env, raw_env  # noqa: E402
+
+_, YGOProDMEnvPool, YGOProGymEnvPool, YGOProGymnasiumEnvPool = py_env(_YGOProEnvSpec, _YGOProEnvPool)
+YGOProRawEnvPool = raw_env(_YGOProEnvPool)
+
+__all__ = ["YGOProEnvSpec", "YGOProEncoder", "init_module", "YGOProDMEnvPool", "YGOProGymEnvPool",
+           "YGOProGymnasiumEnvPool", "YGOProRawEnvPool", "CONFIG_KEYS", "DEFAULT_CONFIG_VALUES", "STATE_KEYS", "ACTION_KEYS"]

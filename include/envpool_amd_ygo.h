@@ -271,6 +271,48 @@ int ep_ygo_emit_records(const ep_ygo_config* cfg, const ygo_raw_state* in, int32
 int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, int32_t msg,
                         const char* option, const uint16_t* card_ids, int32_t n_card_ids);
 
+/* ---- a YGOPro env pool over a caller-supplied duel engine ---------------------------------
+ * AsyncEnvPool<YGOProEnv> (envpool2/core/async_envpool.h:40-190) with the duel engine behind two
+ * callbacks. The engine (ygopro-core, Lua card scripts, the SQLite card database) runs on the host
+ * and is not part of this library; the callbacks run it for one env up to the point where the
+ * reference calls WriteState (YGOProEnv::Reset, ygopro.h:1374-1423; Step, :1452-1494) and describe
+ * what WriteState would read. The pool does the rest: action queue and worker threads
+ * (action_buffer_queue.h:35-85, async_envpool.h:116-129), auto-reset one step after `done`
+ * (:125), current_step_ / info:env_id / elapsed_step (env.h:181-189, 196-222), record emission on
+ * the worker thread, the pinned ring, the encode kernel, and batches handed out in order.
+ *   callbacks   are called from worker threads, never twice at once for the same env; return 0 or
+ *               non-zero for failure (the env's row is then an empty observation, the env counts as
+ *               done and the next recv reports EP_ERR_INVALID beside the batch). Pointers placed in
+ *               *state must stay valid until the same env's next callback returns. env_id,
+ *               elapsed_step and the history of `done` are the pool's: what the engine writes into
+ *               state->env_id / elapsed_step is ignored, state->done is IsDone() (:1428).
+ *   send        SendImpl (:57-80): host arrays env_id[n], action[n] (the reference's `action` key,
+ *               an option index). An env whose previous step is still running on a worker cannot
+ *               be sent again (EP_ERR_INVALID), and an env may appear once per send
+ *               (EP_ERR_DUP_ENV): its duel would otherwise run on two threads at once.
+ *   reset       Reset (:176-189): forced reset of the listed envs.
+ *   recv        Recv (:162-174): the next batch, arrays in _state_keys order + aux:h_card_ids as for
+ *               ep_ygo_collect. batch_size < num_envs: rows in arrival order; batch_size ==
+ *               num_envs (sync): row i is position i of the sent env_id array (:69), and a sync pool
+ *               takes one send / reset per recv.
+ * num_threads <= 0: min(batch_size, hardware threads) (:113-115); thread_affinity_offset < 0: none. */
+typedef struct {
+  void* ctx;
+  int (*reset)(void* ctx, int32_t env_id, ygo_raw_state* state);
+  int (*step)(void* ctx, int32_t env_id, int32_t action, ygo_raw_state* state);
+} ep_ygo_engine;
+typedef struct ep_ygo_pool ep_ygo_pool;
+int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, int32_t num_envs, int32_t batch_size,
+                       int32_t num_threads, int32_t thread_affinity_offset, const ygo_card_data* cards, int32_t n_cards,
+                       ep_ygo_pool** out);
+int ep_ygo_pool_destroy(ep_ygo_pool* pool);
+int ep_ygo_pool_send(ep_ygo_pool* pool, int32_t n, const int32_t* env_id, const int32_t* action);
+int ep_ygo_pool_reset(ep_ygo_pool* pool, int32_t n, const int32_t* env_id);
+int ep_ygo_pool_recv(ep_ygo_pool* pool, int32_t mem_out, ep_batch* out);
+int ep_ygo_pool_set_recv_timeout(ep_ygo_pool* pool, int64_t milliseconds); /* as ep_pool_set_recv_timeout */
+ep_ygo_encoder* ep_ygo_pool_encoder(ep_ygo_pool* pool); /* for ep_ygo_set_timing / ep_ygo_ring_stats */
+int32_t ep_ygo_pool_num_threads(ep_ygo_pool* pool);
+
 #ifdef __cplusplus
 }
 #endif

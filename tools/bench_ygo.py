@@ -168,6 +168,10 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
     res["config5_async_ring"] = run_config5(device)
   except Exception as ex:  # noqa: BLE001
     res["config5_async_ring"] = {"error": repr(ex)}
+  try:
+    res["config5_pool"] = run_config5_pool(device)
+  except Exception as ex:  # noqa: BLE001
+    res["config5_pool"] = {"error": repr(ex)}
   if cpu_seconds > 0:
     from oracle import ygo_oracle
     n_cpu = 2048
@@ -248,6 +252,56 @@ def run_config5(device=0, threads_list=(1, 4, 12, 16), n_envs=1024, batch=512, s
       "gpu_time_hidden_behind_emission": hidden}
     enc.close()
   return out
+
+def run_config5_pool(device=0, threads_list=(4, 16), n_envs=1024, batch=512, batches=120, engine_us=None):
+  """BASELINE config 5 per GPU as a POOL (ep_ygo_pool, envpool_amd/csrc/ygo_pool.hip): async mode,
+  1024 envs, batches of 512, the stand-in duel engine behind the ep_ygo_engine callbacks. The loop
+  is the user's: recv a batch (device views), send an action for every env in it (read back from
+  the batch's info:env_id, 2 KiB). Reports batches/s per worker-thread count."""
+  import numpy as np
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  if engine_us is None:
+    engine_us = float(os.environ.get("EP_YGO_ENGINE_US", "20"))
+  L = capi_ygo.lib()
+  hip = L  # dlsym on the library's handle also finds its dependency libamdhip64's symbols
+  hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+  table = ygo_synth.make_table(1000, seed=0)
+  out = {"envs": n_envs, "batch_size": batch, "engine_us_per_env_step": engine_us, "by_threads": {}}
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  for nt in threads_list:
+    cfg = capi_ygo.default_config(max_batch=batch, ring_depth=0, device_id=device)
+    eng = ygo_synth.SynthEngine(cfg, table, n_envs, seed=5, engine_us=engine_us)
+    eng.set_replay()  # generating a synthetic state costs more than the 20 us "engine": keep it out
+    pool = capi_ygo.YgoPoolC(cfg, eng.engine(), n_envs, batch, table, len(table), num_threads=nt)
+    h = pool.handle
+    pool.set_recv_timeout(60000)
+    ids = np.arange(n_envs, dtype=np.int32)
+    act = np.zeros(batch, dtype=np.int32)
+    got = np.zeros(batch, dtype=np.int32)
+    b = capi.Batch()
+    pool.reset(ids)
+
+    def one():
+      assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      assert hip.hipMemcpy(got.ctypes.data, b.arrays[0].data, 4 * batch, 2) == 0  # 2 = device to host
+      assert L.ep_ygo_pool_send(h, batch, got.ctypes.data, act.ctypes.data) == 0
+    for _ in range(10):
+      one()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+      one()
+    dt = time.perf_counter() - t0
+    for _ in range(n_envs // batch):  # drain
+      assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    out["by_threads"][str(nt)] = {"batches_per_s": batches / dt, "env_steps_per_s": batches * batch / dt,
+                                  "us_per_batch": dt / batches * 1e6}
+    pool.close()
+    eng.close()
+  return out
+
 
 def run_config3_packed(device=0, n_envs=1024, steps_per_env=100, threads=4):
   """BASELINE config 3 (1024 envs, sync: batch = 1024) with host records in the PACKED form:

@@ -452,3 +452,83 @@ int ys_run_producers(void* enc, const ys_ring_api* api, const ep_ygo_config* cfg
   if (emit_seconds_out) *emit_seconds_out = emit;
   return rc;
 }
+
+/* ---- stand-in duel engine behind the ep_ygo_engine callbacks (ep_ygo_pool_create) ---------------
+ * Deterministic per env: the k-th callback for env e produces the synthetic state number
+ * e * 1000003 + k of the generator above; an episode of env e lasts 3 + e % 5 steps; the action of
+ * a step is echoed in win_reason and reward so that a test can see which action reached which env.
+ * A callback may spend `engine_us` microseconds "in the engine" first. States stay valid until the
+ * env's next callback, as the callback contract requires. */
+typedef struct {
+  ep_ygo_config cfg;
+  const ygo_card_data* table;
+  int32_t n_table, num_envs;
+  uint64_t seed;
+  double engine_us;
+  int64_t* calls;
+  int32_t* t_ep;
+  ys_state** cur;
+  int32_t fail_env; /* >= 0: callbacks of this env report failure (tests) */
+  int32_t replay;   /* != 0: every callback of env e hands out the SAME pre-generated state (bench: the
+                       cost of generating a synthetic state is not the engine's) */
+} ys_engine;
+
+void* ys_engine_create(const ep_ygo_config* cfg, const ygo_card_data* table, int32_t n_table, int32_t num_envs,
+                       uint64_t seed, double engine_us) {
+  ys_engine* g = calloc(1, sizeof(*g));
+  g->cfg = *cfg;
+  g->table = table;
+  g->n_table = n_table;
+  g->num_envs = num_envs;
+  g->seed = seed;
+  g->engine_us = engine_us;
+  g->calls = calloc((size_t)num_envs, sizeof(int64_t));
+  g->t_ep = calloc((size_t)num_envs, sizeof(int32_t));
+  g->cur = calloc((size_t)num_envs, sizeof(ys_state*));
+  g->fail_env = -1;
+  return g;
+}
+
+void ys_engine_set_fail_env(void* ctx, int32_t env) { ((ys_engine*)ctx)->fail_env = env; }
+
+void ys_engine_set_replay(void* ctx, int32_t on) {
+  ys_engine* g = (ys_engine*)ctx;
+  g->replay = on;
+  if (on)
+    for (int i = 0; i < g->num_envs; ++i)
+      if (!g->cur[i]) g->cur[i] = ys_gen(g->seed, (int64_t)i * 1000003, &g->cfg, g->table, g->n_table);
+}
+
+void ys_engine_destroy(void* ctx) {
+  ys_engine* g = (ys_engine*)ctx;
+  if (!g) return;
+  for (int i = 0; i < g->num_envs; ++i) ys_free(g->cur[i]);
+  free(g->calls); free(g->t_ep); free(g->cur); free(g);
+}
+
+static int ys_engine_advance(ys_engine* g, int32_t env_id, int reset, int32_t action, ygo_raw_state* out) {
+  if (env_id < 0 || env_id >= g->num_envs) return 1;
+  if (g->engine_us > 0) {
+    const double until = ys_now() + 1e-6 * g->engine_us;
+    while (ys_now() < until) {}
+  }
+  if (env_id == g->fail_env) return 2;
+  ys_state* s = g->cur[env_id];
+  if (!g->replay) {
+    ys_free(s);
+    s = ys_gen(g->seed, (int64_t)env_id * 1000003 + g->calls[env_id], &g->cfg, g->table, g->n_table);
+    g->cur[env_id] = s;
+  }
+  g->calls[env_id] += 1;
+  g->t_ep[env_id] = reset ? 0 : g->t_ep[env_id] + 1;
+  s->raw.done = g->t_ep[env_id] >= 3 + env_id % 5;
+  s->raw.win_reason = reset ? 0 : action;
+  s->raw.reward = reset ? 0.f : (float)(action % 3);
+  *out = s->raw;
+  return 0;
+}
+
+int ys_engine_reset(void* ctx, int32_t env_id, ygo_raw_state* out) { return ys_engine_advance((ys_engine*)ctx, env_id, 1, 0, out); }
+int ys_engine_step(void* ctx, int32_t env_id, int32_t action, ygo_raw_state* out) {
+  return ys_engine_advance((ys_engine*)ctx, env_id, 0, action, out);
+}
