@@ -467,8 +467,8 @@ def main():
     for th in (1, cores):
       c2 = time.perf_counter()
       bench_sync_threadpool(N, SEED, 3, th)
-      per_step = (time.perf_counter() - c2) / 4
-      n_arch = int(max(4, min(2000, 3.0 / per_step)))
+      arch_step_s = (time.perf_counter() - c2) / 4
+      n_arch = int(max(4, min(2000, 3.0 / arch_step_s)))
       c2 = time.perf_counter()
       bench_sync_threadpool(N, SEED, n_arch, th)
       arch[str(th)] = N * (n_arch + 1) / (time.perf_counter() - c2)
