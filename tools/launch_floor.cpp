@@ -118,6 +118,39 @@ int main() {
     printf("(b) kernel writes a host-mapped word, host spins: %.2f us (launch call itself %.2f)\n", med(t), med(tl));
   }
   {
+    // (b') the same kernel as a captured one-node hipGraph, replayed: what "a hipGraph of {step
+    // kernel} per step" would cost (the kernel's argument is fixed at capture, so completion is seen
+    // with hipStreamSynchronize)
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 100; ++i) CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<double> t, tl;
+    for (int i = 0; i < R; ++i) {
+      const double a = now_us();
+      CK(hipGraphLaunch(ge, st));
+      const double b = now_us();
+      CK(hipStreamSynchronize(st));
+      t.push_back(now_us() - a);
+      tl.push_back(b - a);
+    }
+    printf("(b') one-kernel hipGraph replay + hipStreamSynchronize: %.2f us (hipGraphLaunch itself %.2f)\n", med(t), med(tl));
+    std::vector<double> t2;
+    for (int i = 0; i < R; ++i) {
+      const double a = now_us();
+      hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st);
+      CK(hipStreamSynchronize(st));
+      t2.push_back(now_us() - a);
+    }
+    printf("(b'') plain launch of the same kernel + hipStreamSynchronize: %.2f us\n", med(t2));
+    CK(hipGraphExecDestroy(ge));
+    CK(hipGraphDestroy(g));
+  }
+  {
     *bell = 0; *done = 0;
     hipLaunchKernelGGL(k_pingpong, dim3(1), dim3(64), 0, st, d, d + 16, (unsigned)R, 2000000u);
     std::vector<double> t;
