@@ -150,6 +150,23 @@ int main() {
     CK(hipGraphExecDestroy(ge));
     CK(hipGraphDestroy(g));
   }
+  for (int variant = 0; variant < 3; ++variant) {
+    // (e) what hipDeviceSynchronize costs AFTER the launch's completion event has been waited for:
+    // 0 = nothing in between, 1 = hipStreamQuery first, 2 = hipEventQuery first
+    std::vector<double> t, tq;
+    for (int i = 0; i < R; ++i) {
+      hipExtLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, nullptr, ev, 0);
+      CK(hipEventSynchronize(ev));
+      const double q0 = now_us();
+      if (variant == 1) (void)hipStreamQuery(st);
+      if (variant == 2) (void)hipEventQuery(ev);
+      const double a = now_us();
+      CK(hipDeviceSynchronize());
+      t.push_back(now_us() - a);
+      tq.push_back(a - q0);
+    }
+    printf("(e%d) hipDeviceSynchronize after the completion event was waited for: %.2f us (query before it %.2f)\n", variant, med(t), med(tq));
+  }
   {
     *bell = 0; *done = 0;
     hipLaunchKernelGGL(k_pingpong, dim3(1), dim3(64), 0, st, d, d + 16, (unsigned)R, 2000000u);
