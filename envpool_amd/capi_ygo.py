@@ -51,7 +51,7 @@ SYMBOLS = [
   "ep_ygo_action_feats", "ep_ygo_featurize", "ep_ygo_submit", "ep_ygo_collect", "ep_ygo_acquire_slot",
   "ep_ygo_commit_slot", "ep_ygo_sync", "ep_ygo_stream", "ep_ygo_set_timing", "ep_ygo_kernel_time_us",
   "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy", "ep_ygo_submit_device",
-  "ep_ygo_async_begin", "ep_ygo_alloc_record", "ep_ygo_record_done", "ep_ygo_recv", "ep_ygo_set_recv_timeout",
+  "ep_ygo_async_begin", "ep_ygo_async_end", "ep_ygo_alloc_record", "ep_ygo_record_done", "ep_ygo_recv", "ep_ygo_set_recv_timeout",
   "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
   "ep_ygo_commit_slot_packed", "ep_ygo_emit_records_packed",
   "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
@@ -98,6 +98,7 @@ def lib():
     L.ep_ygo_emit_record.argtypes = [C.POINTER(YgoConfig), C.POINTER(RawState), vp]
     L.ep_ygo_emit_records.argtypes = [C.POINTER(YgoConfig), C.POINTER(RawState), i32, vp, vp]
     L.ep_ygo_async_begin.argtypes = [vp, i32]
+    L.ep_ygo_async_end.argtypes = [vp]
     L.ep_ygo_alloc_record.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.ep_ygo_record_done.argtypes = [vp, C.c_uint64]
     L.ep_ygo_recv.argtypes = [vp, i32, C.POINTER(capi.Batch)]

@@ -105,6 +105,7 @@ struct ep_ygo_encoder {
   std::vector<uint64_t> a_committed;           // [ring] 1 + index of the batch whose kernel is enqueued in the slot, 0 = none
   std::condition_variable cv_space, cv_ready;
   int64_t a_recv_timeout_ms = -1;
+  std::atomic<bool> a_closing{false};  // ep_ygo_async_end: waiters leave with an error instead of sleeping on
   std::atomic<uint64_t> a_space_wait_ns{0};
   size_t tab_bytes = 0;
   bool a_packed = false;                          // arrival-ordered mode: records packed back to back (ep_ygo_emit_arrival)
@@ -636,6 +637,20 @@ int ep_ygo_async_begin(ep_ygo_encoder* e, int32_t batch_size) {
   for (size_t i = 0; i < e->slots.size(); ++i) { e->a_done[i].store(0); e->a_bytes[i].store(0); }
   e->a_packed = false;
   e->a_committed.assign(e->slots.size(), 0);
+  e->a_closing.store(false);
+  return EP_OK;
+}
+
+// Shutdown of the arrival-ordered ring: producers sleeping on a full ring and a consumer sleeping
+// on an incomplete batch return EP_ERR_WOULD_BLOCK, and so does every later alloc that would have
+// to wait. For owners that must join their producer threads (ep_ygo_pool_destroy); the ring is
+// usable again after the next ep_ygo_async_begin.
+int ep_ygo_async_end(ep_ygo_encoder* e) {
+  if (!e) return fail(EP_ERR_INVALID, "null encoder");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->a_closing.store(true);
+  e->cv_space.notify_all();
+  e->cv_ready.notify_all();
   return EP_OK;
 }
 
@@ -653,8 +668,9 @@ int ep_ygo_alloc_record(ep_ygo_encoder* e, void** record, uint64_t* ticket) {
     const auto t0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> lk(e->mu);
-      e->cv_space.wait(lk, [&] { return bi + 1 < e->a_recv.load(std::memory_order_acquire) + depth; });
+      e->cv_space.wait(lk, [&] { return e->a_closing.load() || bi + 1 < e->a_recv.load(std::memory_order_acquire) + depth; });
     }
+    if (e->a_closing.load()) return fail(EP_ERR_WOULD_BLOCK, "the arrival-ordered ring was closed (ep_ygo_async_end) while it was full");
     e->a_space_wait_ns.fetch_add(
         (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
         std::memory_order_relaxed);
@@ -716,12 +732,14 @@ int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
   const uint64_t depth = e->slots.size();
   const uint64_t bi = e->a_recv.load(std::memory_order_relaxed);
   const int si = (int)(bi % depth);
-  auto ready = [&] { return e->a_committed[si] == bi + 1; };
+  auto ready = [&] { return e->a_committed[si] == bi + 1 || e->a_closing.load(); };
+  if (e->a_committed[si] != bi + 1 && e->a_closing.load()) return fail(EP_ERR_WOULD_BLOCK, "the arrival-ordered ring was closed");
   if (!ready()) {
     if (e->a_recv_timeout_ms == 0) return fail(EP_ERR_WOULD_BLOCK, "batch %llu is not complete yet", (unsigned long long)bi);
     if (e->a_recv_timeout_ms < 0) e->cv_ready.wait(lk, ready);
     else if (!e->cv_ready.wait_for(lk, std::chrono::milliseconds(e->a_recv_timeout_ms), ready))
       return fail(EP_ERR_WOULD_BLOCK, "batch %llu is not complete yet", (unsigned long long)bi);
+    if (e->a_committed[si] != bi + 1) return fail(EP_ERR_WOULD_BLOCK, "the arrival-ordered ring was closed");
   }
   lk.unlock();
   HIP_TRY(hipSetDevice(e->device));

@@ -251,6 +251,7 @@ int ep_ygo_pool_destroy(ep_ygo_pool* p) {
     for (size_t i = 0; i < p->workers.size(); ++i) p->queue.push_back(Slice{0, -1, 0, false, true, 0});
   }
   p->qcv.notify_all();
+  if (!p->is_sync) (void)ep_ygo_async_end(p->enc);  // workers asleep on a full ring (nobody received) must come back
   for (auto& w : p->workers) w.join();
   int rc = ep_ygo_encoder_destroy(p->enc);
   delete p;

@@ -188,6 +188,10 @@ int ep_ygo_commit_slot(ep_ygo_encoder* enc, int32_t n);
  *                        stay valid until the next ep_ygo_recv. Rows are in arrival order: compare
  *                        with the reference as sets keyed by info:env_id. */
 int ep_ygo_async_begin(ep_ygo_encoder* enc, int32_t batch_size);
+/* Shutdown: producers asleep on a full ring and a consumer asleep on an incomplete batch return
+ * EP_ERR_WOULD_BLOCK (the reference has no counterpart: its destructor joins workers that cannot
+ * be blocked there, because a full queue throws, state_buffer.h:111). */
+int ep_ygo_async_end(ep_ygo_encoder* enc);
 int ep_ygo_alloc_record(ep_ygo_encoder* enc, void** record, uint64_t* ticket);
 int ep_ygo_record_done(ep_ygo_encoder* enc, uint64_t ticket);
 int ep_ygo_recv(ep_ygo_encoder* enc, int32_t mem_out, ep_batch* out);

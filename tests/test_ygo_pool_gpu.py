@@ -115,6 +115,25 @@ def test_async_pool_config5_shape(threads):
   pool.close(); eng.close()
 
 
+def test_destroy_with_a_full_ring_and_nobody_receiving():
+  """Workers asleep on a full ring (the consumer went away) must not keep the pool from closing."""
+  import threading
+  from tools import ygo_synth
+  N, B = 64, 16
+  cfg = capi_ygo.default_config(max_batch=B, ring_depth=2)
+  table = ygo_synth.make_table(1000, seed=0)
+  eng = ygo_synth.SynthEngine(cfg, table, N, seed=4)
+  pool = capi_ygo.YgoPoolC(cfg, eng.engine(), N, B, table, len(table), num_threads=3)
+  pool.reset(np.arange(N, dtype=np.int32))   # 4 batches into a ring of 2: the workers end up waiting
+  import time
+  time.sleep(0.3)
+  t = threading.Thread(target=pool.close)
+  t.start()
+  t.join(timeout=20)
+  assert not t.is_alive()
+  eng.close()
+
+
 def test_engine_failure_is_reported_beside_the_batch():
   from tools import ygo_synth
   N = 8
