@@ -515,6 +515,7 @@ def main():
         "config3_packed": r.get("config3_packed"),
         "config5_async_ring": r.get("config5_async_ring"),
         "config5_pool": r.get("config5_pool"),
+        "config3_pool": r.get("config3_pool"),
       }
       if "cpu_oracle_encodes_per_s_1core" in r:
         ygo["cpu_baseline"] = {"value": r["cpu_oracle_encodes_per_s_1core"], "unit": "encodes/s", "cores": 1, "kind": "port",

@@ -67,6 +67,7 @@ struct ep_ygo_pool {
   std::mutex qmu;
   std::condition_variable qcv;
   std::deque<Slice> queue;
+  alignas(64) std::atomic<int> q_size{0};  // mirror of queue.size() for the workers' spin phase
   std::vector<std::thread> workers;
   // sync pools: the one batch being filled
   std::mutex smu;
@@ -74,8 +75,9 @@ struct ep_ygo_pool {
   uint64_t sync_sent = 0, sync_committed = 0, sync_received = 0;
   char* sync_slot = nullptr;
   int sync_n = 0;
-  std::atomic<int> sync_left{0};
-  std::atomic<uint32_t> sync_bytes{0};
+  alignas(64) std::atomic<int> sync_left{0};        // (own cache lines: every record bumps these two)
+  alignas(64) std::atomic<uint32_t> sync_bytes{0};
+  alignas(64) int pad_after_counters = 0;
   std::vector<uint32_t> sync_offs;
   int sync_commit_rc = EP_OK;
   // outcome of callbacks and emits since the last recv
@@ -130,24 +132,32 @@ void run_slice(ep_ygo_pool* p, const Slice& s, std::vector<uint8_t>& scratch) {
   }
 }
 
+// Takes a fair share of what is queued, at most 8 slices per visit (one lock round trip per slice
+// is what limits a pool whose engine steps are short). `block`: sleep until there is something.
+int take_slices(ep_ygo_pool* p, Slice* mine, bool block) {
+  const size_t nw = p->workers.capacity();  // (reserved to the worker count before the first thread starts)
+  int k = 0;
+  std::unique_lock<std::mutex> lk(p->qmu);
+  if (block) p->qcv.wait(lk, [&] { return !p->queue.empty(); });
+  const size_t share = std::min<size_t>(8, std::max<size_t>(1, p->queue.size() / (2 * nw)));
+  while ((size_t)k < share && !p->queue.empty()) {
+    if (!block && p->queue.front().quit) break;  // quit slices are the workers'
+    mine[k] = p->queue.front();
+    p->queue.pop_front();
+    if (mine[k++].quit) break;  // one quit slice per worker: leave the others theirs
+  }
+  p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
+  return k;
+}
+
 void worker_loop(ep_ygo_pool* p) {  // async_envpool.h:117-128
   std::vector<uint8_t> scratch;
   Slice mine[8];
-  const size_t nw = p->workers.capacity();  // (reserved to the worker count before the first thread starts)
   for (;;) {
-    int k = 0;
-    {
-      // a fair share of what is queued, at most 8 slices per visit: one lock round trip per slice
-      // is what limits a pool whose engine steps are short
-      std::unique_lock<std::mutex> lk(p->qmu);
-      p->qcv.wait(lk, [&] { return !p->queue.empty(); });
-      const size_t share = std::min<size_t>(8, std::max<size_t>(1, p->queue.size() / (2 * nw)));
-      while ((size_t)k < share && !p->queue.empty()) {
-        mine[k] = p->queue.front();
-        p->queue.pop_front();
-        if (mine[k++].quit) break;  // one quit slice per worker: leave the others theirs
-      }
-    }
+    // like the reference's LightweightSemaphore: look for work for a few tens of microseconds
+    // before sleeping in the kernel (a futex wake-up costs more than a short engine step)
+    for (int spin = 0; spin < 4000 && p->q_size.load(std::memory_order_relaxed) == 0; ++spin) __builtin_ia32_pause();
+    const int k = take_slices(p, mine, true);
     for (int i = 0; i < k; ++i) {
       if (mine[i].quit) return;
       run_slice(p, mine[i], scratch);
@@ -193,6 +203,7 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     std::lock_guard<std::mutex> lk(p->qmu);
     for (int i = 0; i < n; ++i)
       p->queue.push_back(Slice{env_id[i], p->is_sync ? i : -1, force_reset ? 0 : action[i], force_reset, false, batch});
+    p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
   }
   p->qcv.notify_all();
   return EP_OK;
@@ -249,6 +260,7 @@ int ep_ygo_pool_destroy(ep_ygo_pool* p) {
   {  // async_envpool.h:144-154: one empty slice per worker
     std::lock_guard<std::mutex> lk(p->qmu);
     for (size_t i = 0; i < p->workers.size(); ++i) p->queue.push_back(Slice{0, -1, 0, false, true, 0});
+    p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
   }
   p->qcv.notify_all();
   if (!p->is_sync) (void)ep_ygo_async_end(p->enc);  // workers asleep on a full ring (nobody received) must come back
@@ -278,8 +290,18 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
   int rc;
   if (p->is_sync) {
     {
-      std::unique_lock<std::mutex> lk(p->smu);
+      std::lock_guard<std::mutex> lk(p->smu);
       if (p->sync_sent == p->sync_received) return fail(EP_ERR_WOULD_BLOCK, "nothing was sent");
+    }
+    if (p->recv_timeout_ms != 0) {
+      // the caller would only sleep until the batch is complete: let it step envs meanwhile
+      static thread_local std::vector<uint8_t> scratch;
+      Slice mine[8];
+      for (int k; (k = take_slices(p, mine, false)) > 0;)
+        for (int i = 0; i < k; ++i) run_slice(p, mine[i], scratch);
+    }
+    {
+      std::unique_lock<std::mutex> lk(p->smu);
       const uint64_t want = p->sync_sent;
       auto ready = [&] { return p->sync_committed == want; };
       if (!ready()) {

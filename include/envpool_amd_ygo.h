@@ -284,7 +284,8 @@ int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, 
  * (action_buffer_queue.h:35-85, async_envpool.h:116-129), auto-reset one step after `done`
  * (:125), current_step_ / info:env_id / elapsed_step (env.h:181-189, 196-222), record emission on
  * the worker thread, the pinned ring, the encode kernel, and batches handed out in order.
- *   callbacks   are called from worker threads, never twice at once for the same env; return 0 or
+ *   callbacks   are called from worker threads (and from inside ep_ygo_pool_recv of a sync pool, whose
+ *               caller helps instead of sleeping), never twice at once for the same env; return 0 or
  *               non-zero for failure (the env's row is then an empty observation, the env counts as
  *               done and the next recv reports EP_ERR_INVALID beside the batch). Pointers placed in
  *               *state must stay valid until the same env's next callback returns. env_id,

@@ -169,6 +169,10 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
   except Exception as ex:  # noqa: BLE001
     res["config5_async_ring"] = {"error": repr(ex)}
   try:
+    res["config3_pool"] = run_config3_pool(device)
+  except Exception as ex:  # noqa: BLE001
+    res["config3_pool"] = {"error": repr(ex)}
+  try:
     res["config5_pool"] = run_config5_pool(device)
   except Exception as ex:  # noqa: BLE001
     res["config5_pool"] = {"error": repr(ex)}
@@ -298,6 +302,45 @@ def run_config5_pool(device=0, threads_list=(4, 16), n_envs=1024, batch=512, bat
       assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
     out["by_threads"][str(nt)] = {"batches_per_s": batches / dt, "env_steps_per_s": batches * batch / dt,
                                   "us_per_batch": dt / batches * 1e6}
+    pool.close()
+    eng.close()
+  return out
+
+
+def run_config3_pool(device=0, threads_list=(4, 16), n_envs=1024, steps=150, engine_us=0.0):
+  """BASELINE config 3 as a POOL (ep_ygo_pool, sync: batch_size = num_envs = 1024): one step =
+  send 1024 actions, the workers run the (stand-in, here free) engine and emit the records, the last
+  one commits the packed slot, recv waits for the encode. PCIe-inclusive, emission included."""
+  import numpy as np
+
+  from envpool_amd import capi, capi_ygo
+  from tools import ygo_synth
+
+  L = capi_ygo.lib()
+  table = ygo_synth.make_table(1000, seed=0)
+  out = {"envs": n_envs, "engine_us_per_env_step": engine_us, "by_threads": {}}
+  ok = (0, capi.EP_ERR_ACTION_CHECK)
+  for nt in threads_list:
+    cfg = capi_ygo.default_config(max_batch=n_envs, ring_depth=0, device_id=device)
+    eng = ygo_synth.SynthEngine(cfg, table, n_envs, seed=5, engine_us=engine_us)
+    eng.set_replay()
+    pool = capi_ygo.YgoPoolC(cfg, eng.engine(), n_envs, n_envs, table, len(table), num_threads=nt)
+    h = pool.handle
+    pool.set_recv_timeout(60000)
+    ids = np.arange(n_envs, dtype=np.int32)
+    act = np.zeros(n_envs, dtype=np.int32)
+    b = capi.Batch()
+    pool.reset(ids)
+    assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+    ts = []
+    for i in range(steps + 20):
+      t0 = time.perf_counter()
+      assert L.ep_ygo_pool_send(h, n_envs, ids.ctypes.data, act.ctypes.data) == 0
+      assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      if i >= 20:
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    out["by_threads"][str(nt)] = {"us_per_step_median": ts[len(ts) // 2] * 1e6, "env_steps_per_s": n_envs / ts[len(ts) // 2]}
     pool.close()
     eng.close()
   return out
