@@ -12,13 +12,15 @@
  * is a valid execution of the reference and the one restated here: every slice
  * is processed at enqueue time, in order.
  *
- * Pinning: the reference's Dummy path needs glog and moodycamel's
+ * PARITY UNPINNED. The reference's Dummy path needs glog and moodycamel's
  * lightweightsemaphore.h, neither of which is in this image, so it cannot be
- * compiled here. This oracle is pinned against the golden
- * traces the survey recorded from the reference (SURVEY.md §8a "Closed form" /
- * "Golden trace" / "Multi-player probe"), committed under tests/golden/.
- * Everything those traces do not cover is "parity unpinned" and rests on the
- * line-by-line citations below.
+ * compiled here, and the reference holds no test or fixture for
+ * this path. The oracle is checked against the traces SURVEY.md §8a recorded
+ * ("Closed form" / "Golden trace" / "Multi-player probe", tests/golden/), but
+ * the survey's build of the reference used stand-in headers for those two
+ * libraries, which by this project's rule pins nothing. What it rests on: the
+ * line-by-line citations below, and agreement with the independently written
+ * threaded restatement in dummy_pool_mt.c.
  */
 #include <stdint.h>
 #include <stdlib.h>
