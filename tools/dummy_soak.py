@@ -44,8 +44,8 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
         # multi-player: one action row per player the env reported in the last batch, the envs in
         # random order and a few of them twice (their items see the same row count, env.h:128-132)
         sel = rng.permutation(np.unique(last_ids)).astype(np.int32)
-        if rng.random() < 0.5:
-          sel = np.concatenate([sel, rng.choice(sel, size=min(3, len(sel)))]).astype(np.int32)
+        if rng.random() < 0.5 and len(sel) < n:  # (a send carries at most num_envs items here)
+          sel = np.concatenate([sel, rng.choice(sel, size=min(3, len(sel), n - len(sel)))]).astype(np.int32)
         penv = np.asarray(want[1]).astype(np.int32)
         a = dummy_action(sel, penv)
         g._send(a); o._send(a)
