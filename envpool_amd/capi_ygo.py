@@ -55,7 +55,7 @@ SYMBOLS = [
   "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
   "ep_ygo_commit_slot_packed", "ep_ygo_emit_records_packed",
   "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
-  "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads",
+  "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads", "ep_ygo_pool_set_env_id_offset",
 ]
 
 # the duel-engine callbacks of ep_ygo_pool_create
@@ -121,6 +121,7 @@ def lib():
     L.ep_ygo_pool_encoder.argtypes = [vp]
     L.ep_ygo_pool_encoder.restype = vp
     L.ep_ygo_pool_num_threads.argtypes = [vp]
+    L.ep_ygo_pool_set_env_id_offset.argtypes = [vp, i32]
     L.ep_ygo_history_push.argtypes = [C.POINTER(YgoConfig), vp, C.POINTER(i32), i32, C.c_char_p, vp, i32]
     _bound = L
   return _bound
@@ -236,6 +237,9 @@ class YgoPoolC:
 
   def set_recv_timeout(self, ms):
     capi._check(self._L.ep_ygo_pool_set_recv_timeout(self._h, ms))
+
+  def set_env_id_offset(self, offset):
+    capi._check(self._L.ep_ygo_pool_set_env_id_offset(self._h, offset))
 
   def send(self, env_id, action):
     env_id = np.ascontiguousarray(env_id, dtype=np.int32)

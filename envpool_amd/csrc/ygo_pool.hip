@@ -58,6 +58,7 @@ struct ep_ygo_pool {
   ep_ygo_engine engine{};
   ep_ygo_encoder* enc = nullptr;
   int N = 0, B = 0;
+  int32_t env_off = 0;  // global id of local env 0 (one pool per GPU, env ids sharded in blocks)
   bool is_sync = false;
   int64_t stride = 0;
   std::unique_ptr<EnvSlot[]> envs;
@@ -89,7 +90,7 @@ namespace {
 
 // One env-step on a worker thread: EnvStep (env.h:162-172) with the engine behind the callbacks.
 void run_slice(ep_ygo_pool* p, const Slice& s, std::vector<uint8_t>& scratch) {
-  EnvSlot& e = p->envs[s.env_id];
+  EnvSlot& e = p->envs[s.env_id - p->env_off];
   const bool reset = s.force_reset || e.done;  // async_envpool.h:125
   e.current_step = reset ? 0 : e.current_step + 1;  // env.h:181-189
   ygo_raw_state st;
@@ -176,13 +177,14 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     p->stamp_val = 1;
   }
   for (int i = 0; i < n; ++i) {
-    const int32_t e = env_id[i];
-    if (e < 0 || e >= p->N) return fail(EP_ERR_INVALID, "env_id[%d] = %d outside [0, %d)", i, e, p->N);
+    const int32_t e = env_id[i] - p->env_off;
+    if (e < 0 || e >= p->N)
+      return fail(EP_ERR_INVALID, "env_id[%d] = %d outside this pool's [%d, %d)", i, env_id[i], p->env_off, p->env_off + p->N);
     if (p->stamp[(size_t)e] == p->stamp_val)
-      return fail(EP_ERR_DUP_ENV, "env %d is named twice in one send: its duel would run on two threads at once", e);
+      return fail(EP_ERR_DUP_ENV, "env %d is named twice in one send: its duel would run on two threads at once", env_id[i]);
     p->stamp[(size_t)e] = p->stamp_val;
     if (p->envs[e].in_flight.load(std::memory_order_acquire))
-      return fail(EP_ERR_INVALID, "env %d is still stepping: receive its state before sending it again", e);
+      return fail(EP_ERR_INVALID, "env %d is still stepping: receive its state before sending it again", env_id[i]);
   }
   uint64_t batch = 0;
   if (p->is_sync) {
@@ -198,7 +200,7 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     p->sync_offs.assign((size_t)n, 0u);
     batch = ++p->sync_sent;
   }
-  for (int i = 0; i < n; ++i) p->envs[env_id[i]].in_flight.store(1, std::memory_order_relaxed);
+  for (int i = 0; i < n; ++i) p->envs[env_id[i] - p->env_off].in_flight.store(1, std::memory_order_relaxed);
   {
     std::lock_guard<std::mutex> lk(p->qmu);
     for (int i = 0; i < n; ++i)
@@ -328,6 +330,17 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
   if (p->emit_refused.exchange(0))
     return fail(EP_ERR_ACTION_CHECK, "a duel state could not be parsed (the reference throws on it): its row is an empty observation");
   return rc;
+}
+
+int ep_ygo_pool_set_env_id_offset(ep_ygo_pool* p, int32_t env_id_offset) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->smu);
+  std::lock_guard<std::mutex> lq(p->qmu);
+  if (!p->queue.empty() || p->sync_sent != 0) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
+  for (int i = 0; i < p->N; ++i)
+    if (p->envs[i].current_step != -1) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
+  p->env_off = env_id_offset;
+  return EP_OK;
 }
 
 ep_ygo_encoder* ep_ygo_pool_encoder(ep_ygo_pool* p) { return p ? p->enc : nullptr; }

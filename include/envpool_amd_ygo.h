@@ -315,6 +315,10 @@ int ep_ygo_pool_send(ep_ygo_pool* pool, int32_t n, const int32_t* env_id, const 
 int ep_ygo_pool_reset(ep_ygo_pool* pool, int32_t n, const int32_t* env_id);
 int ep_ygo_pool_recv(ep_ygo_pool* pool, int32_t mem_out, ep_batch* out);
 int ep_ygo_pool_set_recv_timeout(ep_ygo_pool* pool, int64_t milliseconds); /* as ep_pool_set_recv_timeout */
+/* One pool per GPU, env ids sharded in contiguous blocks (BASELINE config 5: 8192 envs over 8 GPUs =
+ * 1024 per pool): this pool owns the global ids [offset, offset + num_envs). send / reset take global
+ * ids, the callbacks get global ids, info:env_id is global. Before the first send / reset. */
+int ep_ygo_pool_set_env_id_offset(ep_ygo_pool* pool, int32_t env_id_offset);
 ep_ygo_encoder* ep_ygo_pool_encoder(ep_ygo_pool* pool); /* for ep_ygo_set_timing / ep_ygo_ring_stats */
 int32_t ep_ygo_pool_num_threads(ep_ygo_pool* pool);
 

@@ -238,13 +238,13 @@ from bench import NodeBarrier
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 b = NodeBarrier(rank, world, dist)
-assert not os.path.exists(b.path)            # unlinked once every rank has it mapped
 for i in range(300):
   if i % world == rank and i % 10 == 0:
     time.sleep(0.002)                        # a straggler: nobody may pass generation i+1 before it arrives
   b()
   assert int(b.slots.min()) >= i + 1, (i, b.slots)
   assert int(b.slots.max()) <= i + 2, (i, b.slots)   # and nobody can be more than one barrier ahead
+assert not os.path.exists(b.path)            # rank 0 unlinked it before its first barrier call
 b.close(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -115,6 +115,35 @@ def test_async_pool_config5_shape(threads):
   pool.close(); eng.close()
 
 
+def test_env_id_offset_shard():
+  """One pool per GPU owning a block of global env ids (config 5: 8192 envs = 8 x 1024): send takes
+  global ids, info:env_id is global, ids of other shards are refused."""
+  from tools import ygo_synth
+  N, off = 48, 5 * 1024
+  cfg = capi_ygo.default_config(max_batch=N, ring_depth=0)
+  table = ygo_synth.make_table(1000, seed=0)
+  eng = ygo_synth.SynthEngine(cfg, table, N, seed=6)
+  eng.set_env_id_offset(off)
+  model = ygo_synth.EnginePoolModel(cfg, table, N, seed=6)
+  pool = capi_ygo.YgoPoolC(cfg, eng.engine(), N, N, table, len(table), num_threads=3)
+  pool.set_env_id_offset(off)
+  pool.set_recv_timeout(30000)
+  ids = np.arange(off, off + N, dtype=np.int32)
+  with pytest.raises(capi.EpError):
+    pool.reset(np.arange(N, dtype=np.int32))
+  pool.reset(ids)
+  raws = [model.advance(int(e) - off) for e in ids]
+  for r, e in zip(raws, ids):
+    r.env_id = int(e)
+  out = pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+  assert out[0].tolist() == ids.tolist() and out[1].tolist() == ids.tolist()
+  want, status = _expect_rows(cfg, table, raws)
+  assert sum(_row(out, j) == _row(want, j) for j in range(N) if status[j] == 0) == int((status == 0).sum()) > N // 2
+  with pytest.raises(capi.EpError):
+    pool.set_env_id_offset(0)   # too late
+  pool.close(); eng.close()
+
+
 def test_destroy_with_a_full_ring_and_nobody_receiving():
   """Workers asleep on a full ring (the consumer went away) must not keep the pool from closing."""
   import threading

@@ -469,6 +469,7 @@ typedef struct {
   int32_t* t_ep;
   ys_state** cur;
   int32_t fail_env; /* >= 0: callbacks of this env report failure (tests) */
+  int32_t env_off;  /* global id of env 0 (ys_engine_set_env_id_offset) */
   int32_t replay;   /* != 0: every callback of env e hands out the SAME pre-generated state (bench: the
                        cost of generating a synthetic state is not the engine's) */
 } ys_engine;
@@ -490,6 +491,7 @@ void* ys_engine_create(const ep_ygo_config* cfg, const ygo_card_data* table, int
 }
 
 void ys_engine_set_fail_env(void* ctx, int32_t env) { ((ys_engine*)ctx)->fail_env = env; }
+void ys_engine_set_env_id_offset(void* ctx, int32_t off) { ((ys_engine*)ctx)->env_off = off; }
 
 void ys_engine_set_replay(void* ctx, int32_t on) {
   ys_engine* g = (ys_engine*)ctx;
@@ -507,6 +509,7 @@ void ys_engine_destroy(void* ctx) {
 }
 
 static int ys_engine_advance(ys_engine* g, int32_t env_id, int reset, int32_t action, ygo_raw_state* out) {
+  env_id -= g->env_off; /* the pool hands out global ids */
   if (env_id < 0 || env_id >= g->num_envs) return 1;
   if (g->engine_us > 0) {
     const double until = ys_now() + 1e-6 * g->engine_us;

@@ -28,6 +28,7 @@ def lib():
     L.ys_engine_destroy.argtypes = [C.c_void_p]
     L.ys_engine_set_fail_env.argtypes = [C.c_void_p, C.c_int32]
     L.ys_engine_set_replay.argtypes = [C.c_void_p, C.c_int32]
+    L.ys_engine_set_env_id_offset.argtypes = [C.c_void_p, C.c_int32]
     _LIB = L
   return _LIB
 
@@ -107,6 +108,9 @@ class SynthEngine:
   def set_replay(self, on=True):
     """Every callback of an env hands out the same pre-generated state (benchmarks)."""
     lib().ys_engine_set_replay(self.ctx, int(on))
+
+  def set_env_id_offset(self, off):
+    lib().ys_engine_set_env_id_offset(self.ctx, int(off))
 
   def set_fail_env(self, env):
     lib().ys_engine_set_fail_env(self.ctx, env)
