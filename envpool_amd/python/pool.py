@@ -140,6 +140,58 @@ class EnvPoolFrontEnd:
   def xla(self):
     raise RuntimeError("XLA is disabled (jax is not part of this build).")
 
+  # ---- additive: PyTorch tensors in, PyTorch tensors out, nothing crosses PCIe -----------------
+  def _torch_out(self, descs, reset: bool):
+    from ..interop import as_torch
+    import torch
+    dev = torch.device("cuda", self.config.get("device_id", 0))
+    vals = [None if d is None else as_torch(d, dev) for d in descs]
+    return self._to(vals, reset, True)
+
+  def reset_torch(self):
+    """reset() of every env with the batch returned as torch tensors that alias the device ring
+    (valid until `ring_depth - 1` further batches have been received)."""
+    if not hasattr(self, "_recv_device"):
+      raise RuntimeError(f"{type(self).__name__} has no device-resident path")
+    self._reset(self.all_env_ids)
+    descs, _, _ = self._recv_device()
+    return self._torch_out(descs, True)
+
+  def step_torch(self, action, env_id=None):
+    """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
+    key) or a dict of them in the shapes step() takes, `env_id` an int32 CUDA tensor or None for all
+    envs in order. Returns what step() returns, as torch tensors aliasing the device ring. A sync
+    pool stepped as a whole takes no kernel launch (ep_pool_step, the pool's resident kernel)."""
+    import torch
+    if not hasattr(self, "_step_device"):
+      raise RuntimeError(f"{type(self).__name__} has no device-resident path")
+    keys = self._spec._action_keys
+    adict = _flatten_action(action) if isinstance(action, dict) else {keys[-1]: action}
+    dev = torch.device("cuda", self.config.get("device_id", 0))
+    if env_id is None:
+      if not hasattr(self, "_all_env_ids_torch"):
+        self._all_env_ids_torch = torch.from_numpy(self.all_env_ids).to(dev)
+      env_id = self._all_env_ids_torch
+    adict["env_id"] = env_id
+    adict.setdefault("players.env_id", env_id)
+    ptrs, dims, keep = [], [], []
+    for k, spec in zip(keys, self._spec._action_spec):
+      t = adict.get(k)
+      if t is None:  # keys the env never reads may be left out: an empty stand-in of the right length
+        t = adict["players.env_id"] if k.startswith("players.") else env_id
+      want = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}[str(spec[0])]
+      if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f'step_torch: action "{k}" must be a CUDA tensor')
+      if t.dtype != want or not t.is_contiguous():
+        t = t.to(want).contiguous()
+      keep.append(t)
+      ptrs.append(t.data_ptr())
+      dims.append(int(t.shape[0]))
+    # the actions must be complete before the pool reads them: they were produced on torch's stream
+    torch.cuda.current_stream(dev).synchronize()
+    descs, _, _ = self._step_device(ptrs, dims)
+    return self._torch_out(descs, False)
+
   def __repr__(self) -> str:
     cfg = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())
     return f"{type(self).__name__}({cfg})"

@@ -111,3 +111,34 @@ def test_device_views_and_torch_interop():
   for t in range(10):
     assert_batches_equal([None if x is None else x.cpu().numpy() for x in kept[t]], o._recv(), f"on stream t={t}")
     o._send(dummy_action(ids))
+
+
+@pytest.mark.parametrize("n", [512, 300])
+def test_step_torch_front_end(n):
+  """step_torch / reset_torch: a policy on the GPU steps the pool with torch tensors and gets torch
+  tensors back (n = 512 takes the resident-kernel path of ep_pool_step, n = 300 the launch path);
+  same structure as step(), values equal to the oracle's."""
+  import torch
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  env = envpool_amd.make("Dummy-v0", "gym", num_envs=n, seed=5)
+  o = DummyOracle(num_envs=n, seed=5)
+  ids = np.arange(n, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  obs, info = env.reset_torch()
+  o._reset(ids); w = o._recv()
+  assert obs["raw"].is_cuda and obs["raw"].cpu().numpy().tobytes() == w[8].tobytes()
+  la = torch.full((n, 6), 1.5, dtype=torch.float64, device=dev)
+  for t in range(12):
+    obs, rew, term, trunc, info = env.step_torch({"list_action": la})
+    o._send(dummy_action(ids)); w = o._recv()
+    assert info["env_id"].cpu().numpy().tobytes() == w[0].tobytes()
+    assert info["elapsed_step"].cpu().numpy().tobytes() == w[2].tobytes(), t
+    assert obs["raw"].cpu().numpy().tobytes() == w[8].tobytes(), t
+    assert rew.cpu().numpy().tobytes() == w[4].tobytes()
+    assert (term.cpu().numpy() == (w[3] & ~w[7])).all() and trunc.cpu().numpy().tobytes() == w[7].tobytes()
+  # a subset, in another order
+  sel = torch.tensor([7, 3, 200], dtype=torch.int32, device=dev)
+  obs, rew, term, trunc, info = env.step_torch({"list_action": la[:3]}, env_id=sel)
+  o._send(dummy_action(np.array([7, 3, 200], np.int32))); w = o._recv()
+  assert info["env_id"].cpu().numpy().tolist() == [7, 3, 200] and obs["raw"].cpu().numpy().tobytes() == w[8].tobytes()
