@@ -27,7 +27,12 @@ except ImportError:
       return self.step_type == 2
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def _gym_is_new_api() -> bool:
+  # (cached: a failing `import gym` walks sys.path every time, 60 us per step otherwise)
   try:
     import gym
     from packaging import version
@@ -144,8 +149,22 @@ class EnvPoolFrontEnd:
   def _torch_out(self, descs, reset: bool):
     from ..interop import as_torch
     import torch
-    dev = torch.device("cuda", self.config.get("device_id", 0))
-    vals = [None if d is None else as_torch(d, dev) for d in descs]
+    if not hasattr(self, "_torch_views"):
+      self._torch_views = {}
+      self._torch_dev = torch.device("cuda", self.config.get("device_id", 0))
+    cache = self._torch_views  # the ring has ring_depth slots: the same views come round again
+    vals = []
+    for d in descs:
+      if d is None:
+        vals.append(None)
+        continue
+      key = (d[0], tuple(d[1]))
+      t = cache.get(key)
+      if t is None:
+        if len(cache) > 4096:
+          cache.clear()
+        t = cache[key] = as_torch(d, self._torch_dev)
+      vals.append(t)
     return self._to(vals, reset, True)
 
   def reset_torch(self):
@@ -167,19 +186,24 @@ class EnvPoolFrontEnd:
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
     keys = self._spec._action_keys
     adict = _flatten_action(action) if isinstance(action, dict) else {keys[-1]: action}
-    dev = torch.device("cuda", self.config.get("device_id", 0))
+    if not hasattr(self, "_torch_dev"):
+      self._torch_dev = torch.device("cuda", self.config.get("device_id", 0))
+      self._torch_views = {}
+    dev = self._torch_dev
     if env_id is None:
       if not hasattr(self, "_all_env_ids_torch"):
         self._all_env_ids_torch = torch.from_numpy(self.all_env_ids).to(dev)
       env_id = self._all_env_ids_torch
     adict["env_id"] = env_id
     adict.setdefault("players.env_id", env_id)
+    if not hasattr(self, "_torch_want"):
+      names = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}
+      self._torch_want = [names[str(spec[0])] for spec in self._spec._action_spec]
     ptrs, dims, keep = [], [], []
-    for k, spec in zip(keys, self._spec._action_spec):
+    for k, want in zip(keys, self._torch_want):
       t = adict.get(k)
-      if t is None:  # keys the env never reads may be left out: an empty stand-in of the right length
+      if t is None:  # keys the env never reads may be left out: a stand-in of the right length
         t = adict["players.env_id"] if k.startswith("players.") else env_id
-      want = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}[str(spec[0])]
       if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError(f'step_torch: action "{k}" must be a CUDA tensor')
       if t.dtype != want or not t.is_contiguous():

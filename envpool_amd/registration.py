@@ -8,6 +8,10 @@ base_path = os.path.abspath(os.path.dirname(__file__))
 ENV_TYPES = ("dm", "gym", "gymnasium", "raw")
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def _gym_is_new_api() -> bool:
   try:
     import gym
