@@ -67,4 +67,4 @@ def python_api(N=65536, steps=100):
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "api":
-  python_api()
+  python_api(N=int(sys.argv[2]) if len(sys.argv) > 2 else 65536, steps=int(sys.argv[3]) if len(sys.argv) > 3 else 100)
