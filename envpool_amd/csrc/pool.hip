@@ -61,6 +61,7 @@ struct ep_pool {
   int N = 0, B = 0, P = 0, S = 0, Q = 0;
   bool is_sync = false;
   bool direct_host = true;  // EP_DIRECT_HOST=0: always stage host batches through the copy engine
+  int direct_min_rows = 1;  // EP_DIRECT_MIN_ROWS (4096 until round 2: the staged copies cost a small pool 24 us per step)
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   // device state
@@ -689,6 +690,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->device = cfg->device_id;
   if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
+  if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -889,14 +891,14 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   {
     const uint64_t pos = p->alloc_count;
     SlotHost& sh0 = p->slots[(int)((pos / (uint64_t)p->B) % (uint64_t)p->Q)];
-    if (p->direct_host && !cuts && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= 4096 &&
+    if (p->direct_host && !cuts && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= p->direct_min_rows &&
         sh0.alloc_count == 0 && !sh0.has_work && !sh0.host_blk && slot_free_for(p, pos / (uint64_t)p->B)) {
       void* blk = nullptr;
       if ((rc = epc::take_block(p->blocks, &blk))) return rc;
       void *blk_dev = nullptr, *stage_dev = nullptr;
       if (hipHostGetDevicePointer(&blk_dev, blk, 0) == hipSuccess && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
         const char* sd = (const char*)stage_dev;
-        const int pieces = n >= 32768 ? 4 : 2;
+        const int pieces = n >= 32768 ? 4 : n >= 4096 ? 2 : 1;  // (a piece is worth its launch only when the host's share of it is)
         const int step = (((int)n + pieces - 1) / pieces + 255) & ~255;
         for (int c0 = 0; c0 < (int)n && rc == EP_OK; c0 += step) {
           const int cnt = std::min(step, (int)n - c0);

@@ -1,0 +1,41 @@
+"""Blocking host-memory step latency (C ABI through ctypes, numpy in / host block out) at small N."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from envpool_amd import capi
+
+
+def main():
+  L = capi.lib()
+  for N in (8, 64, 256, 1024, 4096):
+    pool = capi.DummyPoolC(num_envs=N, seed=42, device_id=0)
+    h = pool.handle
+    ids = np.arange(N, dtype=np.int32)
+    la = np.full((N, 6), 1.5)
+    z = np.zeros(N, dtype=np.int32)
+    ph = (C.c_void_p * 5)(ids.ctypes.data, ids.ctypes.data, la.ctypes.data, z.ctypes.data, z.ctypes.data)
+    dims = (C.c_int64 * 5)(N, N, N, N, N)
+    batch = capi.Batch()
+    assert L.ep_pool_reset(h, ids.ctypes.data, N, capi.EP_MEM_HOST) == 0
+    assert L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)) == 0
+    L.ep_batch_release(C.byref(batch))
+    ts = []
+    for i in range(1200):
+      t0 = time.perf_counter()
+      assert L.ep_pool_send(h, 5, ph, dims, capi.EP_MEM_HOST) == 0
+      assert L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)) == 0
+      L.ep_batch_release(C.byref(batch))
+      if i >= 200:
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print(f"N={N}: {ts[len(ts) // 2] * 1e6:.1f} us per blocking host step (EP_DIRECT_MIN_ROWS={os.environ.get('EP_DIRECT_MIN_ROWS', 'default')})", flush=True)
+    pool.close()
+
+
+if __name__ == "__main__":
+  main()
