@@ -268,7 +268,7 @@ struct StepArgs {
   const int32_t* env_id;          // [n] global ids (action key 0)
   const int32_t* players_env_id;  // [n] (action key 1; single player => row i belongs to item i)
   const double* list_action;      // [n,6] (action key 2); null: the lanes were compared on the host, see la_ok
-  const uint32_t* la_ok;          // bit i: the six list_action lanes of item i are equal (direct host mode)
+  const uint32_t* la_ok;          // bit la_bit0 + i: the six list_action lanes of item i are equal (host mode)
   EnvRec* env;
   StatPtrs stats;
   SlotPtrs slot;
@@ -279,6 +279,7 @@ struct StepArgs {
   int32_t n;
   int32_t row0;
   int32_t force_reset;
+  int32_t la_bit0;
 };
 
 template <int S_CT>
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
           double2 v0 = la[0], v1 = la[1], v2 = la[2];
           ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
         } else {
-          ok = ((a.la_ok[i >> 5] >> (i & 31)) & 1u) != 0;
+          const int64_t j = (int64_t)a.la_bit0 + i;
+          ok = ((a.la_ok[j >> 5] >> (j & 31)) & 1u) != 0;
         }
         // the reference only reaches the check on the Step branch, not on an auto-reset
         if (!ok && !(rec.state >= episode_len(a.pc.seed, eid))) a.err->action_check = 1u;

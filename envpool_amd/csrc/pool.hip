@@ -448,13 +448,14 @@ int server_start(ep_pool* p, const void* const* arrs) {
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
               int slot, int err_w, int row0, bool force_reset, bool check_dup, const LaunchEvents& le,
-              char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr) {
+              char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr, int la_bit0 = 0) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
   a.players_env_id = d_penv;
   a.list_action = d_la;
   a.la_ok = la_ok;
+  a.la_bit0 = la_bit0;
   a.env = p->d_env;
   a.stats = p->stats;
   a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
@@ -479,12 +480,16 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
 // `cuts`: positions (ascending, in (0, n)) at which the items must be split into separate launches
 // because an env shows up again (host-validated sends); null for device-memory sends, whose
 // kernels check the per-env launch stamps instead.
-// `row_base` / `out_base`: direct host mode sends one batch as several calls (row_base = rows
-// already sent) whose kernels write into a pinned host block instead of the ring slot.
+// `row_base`: host mode sends one batch as several calls (row_base = items already sent).
+// `host_mode`: the send comes from host memory and will most likely be received as host memory: a
+// batch whose first rows arrive this way gets a pinned host block, and every kernel that writes
+// rows of that batch (this send's or a later one's, host or device memory) writes them into the
+// block over PCIe instead of into the ring slot; recv hands the block out without a copy.
+// `la_ok` / `la_bit_base`: host-compared list_action lanes, bit la_bit_base + i for item i.
 int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
                    int n, int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked,
-                   int row_base = 0, char* out_base = nullptr, hipStream_t st = nullptr,
-                   const uint32_t* la_ok = nullptr) {
+                   int row_base = 0, bool host_mode = false, hipStream_t st = nullptr,
+                   const uint32_t* la_ok = nullptr, int la_bit_base = 0) {
   if (n == 0) return EP_OK;
   if (p->poisoned) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
   const uint64_t B = (uint64_t)p->B;
@@ -521,13 +526,24 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     // state_buffer.h:92-95: sync single-player => row = order (index in the sent batch);
     // otherwise rows follow the allocation order.
     int row0 = p->is_sync ? row_base + i0 : (int)(pos % B);
+    SlotHost& sh = p->slots[slot];
+    if (host_mode && !sh.host_blk && sh.alloc_count == 0 && !sh.has_work) {
+      void* blk = nullptr;
+      if ((rc = epc::take_block(p->blocks, &blk))) break;
+      sh.host_blk = blk;
+    }
+    char* out_base = nullptr;
+    if (sh.host_blk) {
+      void* dv = nullptr;
+      if (hipHostGetDevicePointer(&dv, sh.host_blk, 0) != hipSuccess) { rc = fail(EP_ERR_HIP, "pinned result block is not device-mappable"); break; }
+      out_base = (char*)dv;
+    }
     LaunchEvents le;
     if ((rc = begin_launch(p, &le, st))) break;
     rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
                    d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0, force_reset,
-                   !host_checked && !force_reset, le, out_base, st, la_ok ? la_ok + (i0 >> 5) : nullptr);
+                   !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0);
     if (rc != EP_OK) { abandon_launch(p, le); break; }
-    SlotHost& sh = p->slots[slot];
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
@@ -842,8 +858,14 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   if ((rc = stage_begin(p, &a))) return rc;
   char* h = p->h_stage + (size_t)a * p->stage_bytes;
   memcpy(h, env_ids, 4 * (size_t)n);
-  if ((rc = stage_commit(p, a, 4 * (size_t)n))) return rc;
-  rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true, nullptr, true);
+  void* stage_dev = nullptr;
+  if (p->direct_host && p->P == 1 && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
+    // host mode (see ep_pool_send): the kernel reads the ids from the pinned staging area itself
+    rc = enqueue_slices(p, (const int32_t*)stage_dev, nullptr, nullptr, n, 0, true, nullptr, true, 0, /*host_mode=*/true);
+  } else {
+    if ((rc = stage_commit(p, a, 4 * (size_t)n))) return rc;
+    rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true, nullptr, true);
+  }
   int rc2 = stage_release(p, a);
   return rc ? rc : rc2;
 }
@@ -883,49 +905,32 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   char* d = p->d_stage + (size_t)a * p->stage_bytes;
   size_t o0 = 0, o1 = align_up(4 * (size_t)n), o2 = o1 + align_up(4 * (size_t)np_rows);
   size_t total = o2 + 48 * (size_t)n;
-  // Direct host mode: a whole sync batch from host buffers, to be received as host buffers (the
-  // numpy step() of the reference's API). No copy engine: the batch goes in pieces, each copied
-  // into the pinned staging area and stepped by a kernel that READS the staging area and WRITES
-  // the result block over PCIe itself - the two directions and the host's memcpy of the next
-  // piece overlap. (A later recv that asks for device views copies the block into the ring.)
+  // Host mode: a send from host buffers, most likely to be received as host buffers (the numpy
+  // step() / send() of the reference's API). No copy engine in either direction: the send goes in
+  // pieces, each piece's ids copied into the pinned staging area and stepped by a kernel that
+  // READS the staging area and WRITES its rows into the batch's pinned result block over PCIe
+  // itself - the two directions and the host's work on the next piece overlap. (A later recv that
+  // asks for device views copies the block into the ring.)
   {
-    const uint64_t pos = p->alloc_count;
-    SlotHost& sh0 = p->slots[(int)((pos / (uint64_t)p->B) % (uint64_t)p->Q)];
-    if (p->direct_host && !cuts && p->is_sync && p->P == 1 && n == p->B && pos % (uint64_t)p->B == 0 && n >= p->direct_min_rows &&
-        sh0.alloc_count == 0 && !sh0.has_work && !sh0.host_blk && slot_free_for(p, pos / (uint64_t)p->B)) {
-      void* blk = nullptr;
-      if ((rc = epc::take_block(p->blocks, &blk))) return rc;
-      void *blk_dev = nullptr, *stage_dev = nullptr;
-      if (hipHostGetDevicePointer(&blk_dev, blk, 0) == hipSuccess && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
-        const char* sd = (const char*)stage_dev;
-        const int pieces = n >= 32768 ? 4 : n >= 4096 ? 2 : 1;  // (a piece is worth its launch only when the host's share of it is)
-        const int step = (((int)n + pieces - 1) / pieces + 255) & ~255;
-        for (int c0 = 0; c0 < (int)n && rc == EP_OK; c0 += step) {
-          const int cnt = std::min(step, (int)n - c0);
-          memcpy(h + o0 + 4 * (size_t)c0, (const int32_t*)arrays[0] + c0, 4 * (size_t)cnt);
-          memcpy(h + o1 + 4 * (size_t)c0, (const int32_t*)arrays[1] + c0, 4 * (size_t)cnt);
-          // list_action only matters through "are its six lanes equal" (dummy_envpool.h:187-192):
-          // the comparison is done here, while the 48 bytes per env pass through the host's cache
-          // anyway, and one bit per env crosses PCIe instead (whether a failure counts - only on
-          // the Step branch - is still decided by the kernel, which knows the env's state)
-          la_lanes_equal((const double*)arrays[2] + 6 * (size_t)c0, cnt, (uint32_t*)(h + o2) + (c0 >> 5));
-          rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
-                              nullptr, true, c0, (char*)blk_dev, nullptr, (const uint32_t*)(sd + o2) + (c0 >> 5));
-        }
-        if (rc == EP_OK) {
-          sh0.host_blk = blk;
-        } else {
-          // kernels of earlier pieces may still be writing the block over PCIe: let them finish
-          // before it can be handed to anybody else; the queue counters of those pieces stand, so
-          // the pool refuses further work
-          (void)hipStreamSynchronize(p->stream);
-          p->poisoned = true;
-          epc::give_block(p->blocks, blk);
-        }
-        int rc2 = stage_release(p, a);
-        return rc ? rc : rc2;
+    void* stage_dev = nullptr;
+    if (p->direct_host && p->P == 1 && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
+      const char* sd = (const char*)stage_dev;
+      const int pieces = cuts ? 1 : n >= 32768 ? 4 : n >= 4096 ? 2 : 1;  // (a piece is worth its launch only when the host's share of it is)
+      const int step = (((int)n + pieces - 1) / pieces + 255) & ~255;
+      for (int c0 = 0; c0 < (int)n && rc == EP_OK; c0 += step) {
+        const int cnt = std::min(step, (int)n - c0);
+        memcpy(h + o0 + 4 * (size_t)c0, (const int32_t*)arrays[0] + c0, 4 * (size_t)cnt);
+        memcpy(h + o1 + 4 * (size_t)c0, (const int32_t*)arrays[1] + c0, 4 * (size_t)cnt);
+        // list_action only matters through "are its six lanes equal" (dummy_envpool.h:187-192):
+        // the comparison is done here, while the 48 bytes per env pass through the host's cache
+        // anyway, and one bit per env crosses PCIe instead (whether a failure counts - only on
+        // the Step branch - is still decided by the kernel, which knows the env's state)
+        la_lanes_equal((const double*)arrays[2] + 6 * (size_t)c0, cnt, (uint32_t*)(h + o2) + (c0 >> 5));
+        rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
+                            cuts, true, c0, /*host_mode=*/true, nullptr, (const uint32_t*)(sd + o2), c0);
       }
-      epc::give_block(p->blocks, blk);  // not mappable: the staged way below
+      int rc2 = stage_release(p, a);
+      return rc ? rc : rc2;
     }
   }
   // players.action / players.id (arrays[3], arrays[4]) are never read by DummyEnv::Step
@@ -1109,7 +1114,8 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     epc::give_block(p->blocks, sh.host_blk);
     sh.host_blk = nullptr;
   }
-  const bool one_sync = mem == EP_MEM_HOST && p->P == 1 && !consumer;
+  const bool filled_blk = sh.host_blk != nullptr;  // (still set: wanted as host memory, by the host)
+  const bool one_sync = mem == EP_MEM_HOST && p->P == 1 && !consumer && !filled_blk;
   if (sh.has_work && !consumer && !one_sync)
     if ((rc = wait_launch(p, sh.launch_id, &lk))) return rc;
   if (p->P > 1) nplayers = sh.mp_word >= 0 ? p->h_slot_players[sh.mp_word] : 0;
@@ -1120,6 +1126,11 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     int64_t cur = 0;
     bool any = false;
     auto zero_rows = [&](int64_t a, int64_t b) -> int {
+      if (filled_blk) {  // the kernels of this batch are done (waited for above): plain host stores
+        for (int k = 0; k < 11; ++k)
+          memset((char*)sh.host_blk + p->key_off[k] + (size_t)a * p->key_rowbytes[k], 0, (size_t)(b - a) * p->key_rowbytes[k]);
+        return EP_OK;
+      }
       p->stream_extra = true;
       for (int k = 0; k < 11; ++k) {
         char* base = p->d_ring + (size_t)slot * p->slot_stride + p->key_off[k];
@@ -1172,6 +1183,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     if (!filled && (rc = epc::take_block(p->blocks, &blk))) return rc;
     char* src = p->d_ring + (size_t)slot * p->slot_stride;
     if (filled) {
+      // nothing to copy, and the launches that wrote it were waited for above
     } else if ((size_t)nrows * 2 >= (size_t)p->B) {
       HIP_TRY(hipMemcpyAsync(blk, src, p->slot_stride, hipMemcpyDeviceToHost, p->stream));
     } else {
@@ -1180,7 +1192,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
         if (r) HIP_TRY(hipMemcpyAsync((char*)blk + p->key_off[k], src + p->key_off[k], r * p->key_rowbytes[k], hipMemcpyDeviceToHost, p->stream));
       }
     }
-    if ((rc = sync_stream_unlocked(p, &lk))) { epc::give_block(p->blocks, blk); return rc; }
+    if (!filled && (rc = sync_stream_unlocked(p, &lk))) { epc::give_block(p->blocks, blk); return rc; }
     if (one_sync) status = status_of_err_bits(take_err_bits(p, ew), "recv");
     out->owner = new HostBlockOwner{p->blocks, blk};
     base = (char*)blk;

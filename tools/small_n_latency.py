@@ -37,5 +37,37 @@ def main():
     pool.close()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
   main()
+
+
+def async_small():
+  """An async pool's loop through host memory: recv a batch, send its envs back."""
+  L = capi.lib()
+  for N, B in ((64, 16), (1024, 256), (8192, 2048)):
+    pool = capi.DummyPoolC(num_envs=N, batch_size=B, seed=42, device_id=0)
+    h = pool.handle
+    ids = np.arange(N, dtype=np.int32)
+    la = np.full((B, 6), 1.5)
+    z = np.zeros(B, dtype=np.int32)
+    batch = capi.Batch()
+    assert L.ep_pool_reset(h, ids.ctypes.data, N, capi.EP_MEM_HOST) == 0
+    ts = []
+    got = np.zeros(B, dtype=np.int32)
+    for i in range(1200):
+      t0 = time.perf_counter()
+      assert L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)) == 0
+      C.memmove(got.ctypes.data, batch.arrays[0].data, 4 * B)
+      L.ep_batch_release(C.byref(batch))
+      ph = (C.c_void_p * 5)(got.ctypes.data, got.ctypes.data, la.ctypes.data, z.ctypes.data, z.ctypes.data)
+      dims = (C.c_int64 * 5)(B, B, B, B, B)
+      assert L.ep_pool_send(h, 5, ph, dims, capi.EP_MEM_HOST) == 0
+      if i >= 200:
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print(f"async N={N} B={B}: {ts[len(ts) // 2] * 1e6:.1f} us per recv + send through host memory", flush=True)
+    pool.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "async":
+  async_small()
