@@ -45,17 +45,28 @@ struct MpScratch {
 
 __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int32_t env_off, int32_t N,
                               unsigned long long* counts, uint32_t epoch) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= np_rows) return;
-  int32_t local = penv[j] - env_off;
-  if (local < 0 || local >= N) return;  // rows of envs this pool does not own match nothing
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int32_t local = -1;
+  if (j < np_rows) local = penv[j] - env_off;
+  const bool valid = local >= 0 && local < N;  // rows of envs this pool does not own match nothing
+  // rows of one env usually sit next to each other (they are the previous batch's
+  // info:players.env_id): the first lane of a run adds the whole run, the others add nothing.
+  // Two atomics on one address from neighbouring lanes serialise in the L2; at two rows per env
+  // the histogram took 9 us instead of 2.7.
+  const int32_t prev = __shfl_up(local, 1, 64);
+  const bool head = valid && (lane == 0 || prev != local);
+  const unsigned long long bounds = __ballot(head || !valid);
+  if (!head) return;
+  const unsigned long long above = lane == 63 ? 0ull : bounds & ~((2ull << lane) - 1ull);
+  const int end = above ? __builtin_ctzll(above) : 64;
   // two single-shot atomics, no retry loop: the max moves a counter of an older send to
-  // {epoch, 0} and leaves one of this send alone; then the row is added. Epochs only grow between
+  // {epoch, 0} and leaves one of this send alone; then the rows are added. Epochs only grow between
   // clears of the array (the host clears it when its 32-bit epoch wraps), and any number of rows
   // may name the same env without the threads starving each other.
   unsigned long long* c = counts + local;
   atomicMax(c, (unsigned long long)epoch << 32);
-  atomicAdd(c, 1ull);
+  atomicAdd(c, (unsigned long long)(end - lane));
 }
 
 struct MpFusedArgs {

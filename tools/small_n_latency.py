@@ -71,3 +71,38 @@ def async_small():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "async":
   async_small()
+
+
+def mp_small():
+  """Multi-player pools through host memory (numpy in and out), blocking step."""
+  from envpool_amd.capi import DummyPoolC
+  for N in (64, 1024, 8192):
+    pool = DummyPoolC(num_envs=N, seed=42, device_id=0, max_num_players=3)
+    ids = np.arange(N, dtype=np.int32)
+    pool._reset(ids)
+    out = pool._recv()
+    L = capi.lib()
+    h = pool.handle
+    batch = capi.Batch()
+    ts = []
+    penv = np.ascontiguousarray(out[1])
+    la = np.full((N, 6), 1.5)
+    for i in range(700):
+      z = np.zeros(len(penv), dtype=np.int32)
+      ph = (C.c_void_p * 5)(ids.ctypes.data, penv.ctypes.data, la.ctypes.data, z.ctypes.data, z.ctypes.data)
+      dims = (C.c_int64 * 5)(N, len(penv), N, len(penv), len(penv))
+      t0 = time.perf_counter()
+      assert L.ep_pool_send(h, 5, ph, dims, capi.EP_MEM_HOST) == 0
+      assert L.ep_pool_recv(h, capi.EP_MEM_HOST, C.byref(batch)) == 0
+      t1 = time.perf_counter()
+      penv = np.ctypeslib.as_array(C.cast(batch.arrays[1].data, C.POINTER(C.c_int32)), shape=(batch.num_player_rows,)).copy()
+      L.ep_batch_release(C.byref(batch))
+      if i >= 100:
+        ts.append(t1 - t0)
+    ts.sort()
+    print(f"multi-player P=3 N={N}: {ts[len(ts) // 2] * 1e6:.1f} us per blocking host step", flush=True)
+    pool.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mp":
+  mp_small()
