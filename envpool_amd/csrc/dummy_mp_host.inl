@@ -16,7 +16,8 @@ int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count) {
 }
 
 int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked) {
+               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked,
+               bool host_mode, const uint32_t* la_ok) {
   const uint64_t B = (uint64_t)p->B;
   // one histogram per send (ParseAction scans the WHOLE players.env_id array for every env,
   // env.h:128-132), tagged with a per-pool send counter
@@ -45,17 +46,31 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     int row0 = (int)(pos % B);  // rows follow the allocation order: order == -1 whenever P > 1 (async_envpool.h:69,95)
     SlotHost& sh = p->slots[slot];
     const int word = err_index(p, bi);
+    // host mode (see enqueue_slices): the batch's rows go into a pinned host block
+    if (host_mode && !sh.host_blk && sh.alloc_count == 0 && !sh.has_work) {
+      void* blk = nullptr;
+      if (int rc = epc::take_block(p->blocks, &blk)) return rc;
+      sh.host_blk = blk;
+    }
+    char* out_base = nullptr;
+    if (sh.host_blk) {
+      void* dv = nullptr;
+      if (hipHostGetDevicePointer(&dv, sh.host_blk, 0) != hipSuccess) return fail(EP_ERR_HIP, "pinned result block is not device-mappable");
+      out_base = (char*)dv;
+    }
     epk::MpFusedArgs a;
     a.env_id = d_env_id + i0;
     a.players_env_id = nullptr;
     a.list_action = d_la ? d_la + (size_t)i0 * 6 : nullptr;
+    a.la_ok = (!d_la && !force_reset) ? la_ok : nullptr;
+    a.la_bit0 = i0;
     a.sc = p->mp_sc;
     a.count_epoch = count_epoch;
     a.tile_epoch = next_stamp(p);
     a.ticket_base = p->mp_ticket_total;
     a.env = p->d_env;
     a.stats = p->stats;
-    a.slot = host_slot_ptrs(p, slot);
+    a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
     a.err = p->d_err + word;
     a.stamp = (!host_checked && !force_reset) ? p->d_stamp : nullptr;
     a.stamp_val = a.tile_epoch;

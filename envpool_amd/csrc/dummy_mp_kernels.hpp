@@ -72,7 +72,8 @@ __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int
 struct MpFusedArgs {
   const int32_t* env_id;          // [n] items of this launch
   const int32_t* players_env_id;  // [n] single-player only (row i belongs to item i); else unused
-  const double* list_action;      // [n,6]; null on a forced reset
+  const double* list_action;      // [n,6]; null on a forced reset, or when the lanes were compared on the host (la_ok)
+  const uint32_t* la_ok;          // bit la_bit0 + i: the six list_action lanes of item i are equal (host mode); else null
   MpScratch sc;
   uint32_t count_epoch;   // epoch of the histogram of this send
   uint32_t tile_epoch;    // epoch of this launch's look-back granules (never 0)
@@ -87,6 +88,7 @@ struct MpFusedArgs {
   uint32_t* slot_players;  // device: player rows in the slot so far (read by tile 0 unless first_segment, written by the last tile)
   uint32_t* host_players;  // host-visible copy written by the last tile (may be null)
   int32_t n, row0, force_reset, P, first_segment, num_tiles;
+  int32_t la_bit0;
   int32_t static_tiles;  // tile id = blockIdx.x (every tile of the launch fits on the device at once)
 };
 
@@ -133,9 +135,15 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
           const unsigned long long c = a.sc.counts[local];
           action_num = (uint32_t)(c >> 32) == a.count_epoch ? (int32_t)(uint32_t)c : 0;
         }
-        const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
-        const double2 v0 = la[0], v1 = la[1], v2 = la[2];
-        const bool ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        bool ok;
+        if (a.list_action) {
+          const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
+          const double2 v0 = la[0], v1 = la[1], v2 = la[2];
+          ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        } else {
+          const int64_t j = (int64_t)a.la_bit0 + i;
+          ok = ((a.la_ok[j >> 5] >> (j & 31)) & 1u) != 0;
+        }
         if (!ok) a.err->action_check = 1u;
       }
       if (!a.force_reset && a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;

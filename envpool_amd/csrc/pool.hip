@@ -148,7 +148,8 @@ struct ep_pool {
 
 namespace epk_mp {
 int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
-               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked);
+               int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked,
+               bool host_mode, const uint32_t* la_ok);
 }
 
 namespace {
@@ -507,7 +508,7 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
 
   int rc = EP_OK;
   if (p->P > 1) {
-    rc = epk_mp::enqueue_mp(p, d_env_id, d_penv, d_la, n, np_rows, force_reset, cuts, host_checked);
+    rc = epk_mp::enqueue_mp(p, d_env_id, d_penv, d_la, n, np_rows, force_reset, cuts, host_checked, host_mode, la_ok);
     p->cv.notify_all();
     return rc;
   }
@@ -859,7 +860,7 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   char* h = p->h_stage + (size_t)a * p->stage_bytes;
   memcpy(h, env_ids, 4 * (size_t)n);
   void* stage_dev = nullptr;
-  if (p->direct_host && p->P == 1 && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
+  if (p->direct_host && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
     // host mode (see ep_pool_send): the kernel reads the ids from the pinned staging area itself
     rc = enqueue_slices(p, (const int32_t*)stage_dev, nullptr, nullptr, n, 0, true, nullptr, true, 0, /*host_mode=*/true);
   } else {
@@ -913,8 +914,19 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   // asks for device views copies the block into the ring.)
   {
     void* stage_dev = nullptr;
-    if (p->direct_host && p->P == 1 && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
+    if (p->direct_host && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
       const char* sd = (const char*)stage_dev;
+      if (p->P > 1) {
+        // multi-player: ParseAction scans the WHOLE players.env_id array for every env
+        // (env.h:128-132), so the send stays in one piece
+        memcpy(h + o0, arrays[0], 4 * (size_t)n);
+        memcpy(h + o1, arrays[1], 4 * (size_t)np_rows);
+        la_lanes_equal((const double*)arrays[2], (int)n, (uint32_t*)(h + o2));
+        rc = enqueue_slices(p, (const int32_t*)(sd + o0), (const int32_t*)(sd + o1), nullptr, (int)n, (int)np_rows, false, cuts,
+                            true, 0, /*host_mode=*/true, nullptr, (const uint32_t*)(sd + o2), 0);
+        int rc2 = stage_release(p, a);
+        return rc ? rc : rc2;
+      }
       const int pieces = cuts ? 1 : n >= 32768 ? 4 : n >= 4096 ? 2 : 1;  // (a piece is worth its launch only when the host's share of it is)
       const int step = (((int)n + pieces - 1) / pieces + 255) & ~255;
       for (int c0 = 0; c0 < (int)n && rc == EP_OK; c0 += step) {
@@ -1556,6 +1568,8 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   a.env_id = env_id;
   a.players_env_id = players_env_id;
   a.list_action = force_reset ? nullptr : list_action;
+  a.la_ok = nullptr;
+  a.la_bit0 = 0;
   a.sc = ms;
   a.count_epoch = epoch;
   a.tile_epoch = epoch;
