@@ -117,6 +117,25 @@ def batch_to_numpy(b: Batch):
   return out
 
 
+_TYPESTR = None
+
+
+def batch_to_descs(b: Batch):
+  """Device batch -> list of (ptr, shape, typestr) descriptors in key order (obs:dyn -> None), the
+  form envpool_amd.interop.as_torch takes."""
+  global _TYPESTR
+  if _TYPESTR is None:
+    _TYPESTR = {k: np.dtype(v).str for k, v in _NP.items()}
+  out = []
+  for k in range(b.num_keys):
+    a = b.arrays[k]
+    if a.dtype == EP_CONTAINER_I32:
+      out.append(None)
+      continue
+    out.append((a.data or 0, tuple(a.shape[i] for i in range(a.ndim)), _TYPESTR[a.dtype]))
+  return out
+
+
 class DummyPoolC:
   """Thin object wrapper over the raw C entry points (host-memory flavour)."""
 

@@ -259,3 +259,10 @@ class YgoPoolC:
     self._L.ep_batch_release(C.byref(b))
     self.last_status = rc
     return out
+
+  def recv_device(self, allow=()):
+    """The next batch as device views: (ptr, shape, typestr) per key, valid until the next recv."""
+    b = capi.Batch()
+    rc = capi._check(self._L.ep_ygo_pool_recv(self._h, capi.EP_MEM_DEVICE, C.byref(b)), allow=allow)
+    self.last_status = rc
+    return capi.batch_to_descs(b), b.num_rows

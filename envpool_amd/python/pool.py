@@ -176,6 +176,14 @@ class EnvPoolFrontEnd:
     descs, _, _ = self._recv_device()
     return self._torch_out(descs, True)
 
+  def recv_torch(self, reset: bool = False):
+    """recv() with the batch as torch tensors aliasing device memory (valid until the next recv of
+    a YGOPro pool, until `ring_depth - 1` further batches of a Dummy pool)."""
+    if not hasattr(self, "_recv_device"):
+      raise RuntimeError(f"{type(self).__name__} has no device-resident path")
+    descs, _, _ = self._recv_device()
+    return self._torch_out(descs, reset)
+
   def step_torch(self, action, env_id=None):
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
     key) or a dict of them in the shapes step() takes, `env_id` an int32 CUDA tensor or None for all

@@ -206,6 +206,15 @@ class _YGOProEnvPool:
     self.last_h_card_ids = out[16]
     return out[:16]
 
+  def _recv_device(self):
+    """Additive: the next batch as device views (descriptors for envpool_amd.interop.as_torch): the
+    policy that consumes the observations lives on the GPU, the actions it picks go back through
+    `_send` as host arrays (the duel engine is on the host)."""
+    from .. import capi
+    descs, rows = self._pool.recv_device(allow=(capi.EP_ERR_ACTION_CHECK,))
+    self.last_h_card_ids = descs[16]
+    return descs[:16], rows, rows
+
 
 from ..python.api import py_env, raw_env  # noqa: E402
 

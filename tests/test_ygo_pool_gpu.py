@@ -206,6 +206,11 @@ def test_make_ygopro_with_init_module():
     env.send(np.full(5, 2, np.int32), np.array([9, 1, 4, 30, 2], np.int32))
     obs, rew, term, trunc, info = env.recv()
     assert info["env_id"].tolist() == [9, 1, 4, 30, 2] and (info["win_reason"] == 2).all()
+    # observations for a policy on the GPU: torch views of the encoder's output, actions back as numpy
+    env.send(np.full(N, 3, np.int32))
+    obs_t, rew_t, term_t, trunc_t, info_t = env.recv_torch()
+    assert obs_t["cards_"].is_cuda and tuple(obs_t["cards_"].shape) == (N, 150, 39)
+    assert (info_t["win_reason"] == 3).all().item() and info_t["env_id"].cpu().tolist() == list(range(N))
     env.close()
   finally:
     ygopro.init_module(None, None)
