@@ -35,49 +35,17 @@ STATE_KEYS: List[str] = [
 ACTION_KEYS: List[str] = ["env_id", "players.env_id", "action"]
 
 
-def _spec(dtype, shape, lo, hi):
-  # (dtype, shape, (lo, hi), (elementwise lo, elementwise hi)) — py_envpool.h:102-125
-  return (np.dtype(dtype), list(shape), (lo, hi), ([], []))
+from .._loader import load_library  # noqa: E402
+
+load_library()  # fail loudly before the pybind module tries to resolve its symbols
+
+from .ygopro_envpool import _YGOProEnvSpec, _YGOProNativePool  # noqa: E402
+
+assert list(_YGOProEnvSpec._config_keys) == CONFIG_KEYS and list(_YGOProEnvSpec._state_keys) == STATE_KEYS
 
 
-class _YGOProEnvSpec:
-  """Same attributes as the pybind `_YGOProEnvSpec` (py_envpool.h:269-278)."""
-
-  _config_keys = CONFIG_KEYS
-  _default_config_values = DEFAULT_CONFIG_VALUES
-  _state_keys = STATE_KEYS
-  _action_keys = ACTION_KEYS
-
-  def __init__(self, config_values: Sequence[Any] = DEFAULT_CONFIG_VALUES):
-    if len(config_values) != len(CONFIG_KEYS):
-      raise ValueError(f"_YGOProEnvSpec expects {len(CONFIG_KEYS)} config values, got {len(config_values)}")
-    conf = dict(zip(CONFIG_KEYS, config_values))
-    if conf["batch_size"] > conf["num_envs"]:  # env_spec.h:74-79
-      raise ValueError(f"It is required that batch_size <= num_envs, got num_envs = {conf['num_envs']}, "
-                       f"batch_size = {conf['batch_size']}")
-    if conf["batch_size"] == 0:
-      conf["batch_size"] = conf["num_envs"]
-    for k in ("max_options", "max_cards", "n_history_actions", "max_multi_select"):
-      if conf[k] < 1:
-        raise ValueError(f"{k} must be >= 1")
-    self._conf = conf
-    self._config_values = tuple(conf[k] for k in CONFIG_KEYS)
-    nf = 9 + 2 * conf["max_multi_select"]  # ygopro.h:1189
-    self.n_action_feats = nf
-    self._state_spec = (
-      _spec(np.int32, [], _INT_MIN, _INT_MAX), _spec(np.int32, [-1], _INT_MIN, _INT_MAX),
-      _spec(np.int32, [], _INT_MIN, _INT_MAX), _spec(np.bool_, [], False, True),
-      _spec(np.float32, [-1], _F32_MIN, _F32_MAX), _spec(np.float32, [-1], 0.0, 1.0),
-      _spec(np.int32, [], _INT_MIN, _INT_MAX), _spec(np.bool_, [], False, True),
-      _spec(np.uint8, [conf["max_cards"] * 2, 39], 0, 255), _spec(np.uint8, [8], 0, 255),
-      _spec(np.uint8, [conf["max_options"], nf], 0, 255), _spec(np.uint8, [conf["n_history_actions"], nf], 0, 255),
-      _spec(np.int32, [], 0, conf["max_options"] - 1), _spec(np.int32, [], 0, 1), _spec(np.int32, [], 0, 1),
-      _spec(np.int32, [], -1, 1),
-    )
-    self._action_spec = (
-      _spec(np.int32, [], _INT_MIN, _INT_MAX), _spec(np.int32, [-1], _INT_MIN, _INT_MAX),  # env_spec.h:33-34
-      _spec(np.int32, [], 0, conf["max_options"] - 1),  # ygopro.h:1205-1206
-    )
+def _conf_of(spec) -> Dict[str, Any]:
+  return dict(zip(CONFIG_KEYS, spec._config_values))
 
 
 from ..python.spec import make_spec_class  # noqa: E402
@@ -94,7 +62,7 @@ class YGOProEncoder:
   def __init__(self, spec: _YGOProEnvSpec, card_table, device_id: int = 0, max_batch: int = 0, ring_depth: int = 4):
     from .. import capi_ygo  # needs the HIP library: fails loudly without it
     self._capi = capi_ygo
-    c = spec._conf
+    c = _conf_of(spec)
     self.spec = spec
     self.cfg = capi_ygo.default_config(
       max_cards=c["max_cards"], max_options=c["max_options"], n_history_actions=c["n_history_actions"],
@@ -136,10 +104,10 @@ class YGOProEncoder:
     return d
 
 
-_MODULE = {"engine_factory": None, "card_table": None, "device_id": 0}
+_MODULE = {"engine_factory": None, "card_table": None, "device_id": 0, "env_id_offset": 0}
 
 
-def init_module(engine_factory, card_table, device_id: int = 0) -> None:
+def init_module(engine_factory, card_table, device_id: int = 0, env_id_offset: int = 0) -> None:
   """Counterpart of the reference's `init_module(db_path, code_list_file, decks)`
   (envpool2/ygopro/ygopro.h:1030-1064, called once before any pool is made): tells this package
   where the duel engine and the card data come from, since neither is part of envpool_amd.
@@ -149,32 +117,30 @@ def init_module(engine_factory, card_table, device_id: int = 0) -> None:
   (include/envpool_amd_ygo.h) or Python callables (those hold the GIL: fine for tests, not for
   throughput); `owner` anything that must stay alive as long as the pool.
   `card_table`: sequence of (code, type, level, attribute, race, attack, defense, card_id) or a
-  ctypes array of `capi_ygo.CardData` — `cards_` / `card_ids_` after the reference's init_module."""
-  _MODULE.update(engine_factory=engine_factory, card_table=card_table, device_id=device_id)
+  ctypes array of `capi_ygo.CardData` — `cards_` / `card_ids_` after the reference's init_module.
+  `env_id_offset`: this process's pool owns the global env ids [offset, offset + num_envs) (one
+  process per GPU, ids sharded in blocks)."""
+  _MODULE.update(engine_factory=engine_factory, card_table=card_table, device_id=device_id, env_id_offset=env_id_offset)
 
 
-class _YGOProEnvPool:
+class _YGOProEnvPool(_YGOProNativePool):
   """The raw boundary of the reference's pybind `_YGOProEnvPool` (py_envpool.h:279-287): `_spec`,
-  `_state_keys`, `_action_keys`, `_send(list)`, `_recv() -> list`, `_reset(env_ids)`, over
-  `ep_ygo_pool` (envpool_amd/csrc/ygo_pool.hip). `_recv` returns the 16 arrays of `_state_keys`;
-  the additive `aux:h_card_ids` of the last batch is kept in `last_h_card_ids`."""
+  `_state_keys`, `_action_keys`, `_send(list)`, `_recv() -> list`, `_reset(env_ids)` - the pybind
+  class of envpool_amd/csrc/py_ygopro.cpp over `ep_ygo_pool` (ygo_pool.hip), constructed from a spec
+  alone as the reference's is: the engine and the card table come from `init_module`. `_recv`
+  returns the 16 arrays of `_state_keys` as numpy views of the pinned result block (no copy); the
+  additive `aux:h_card_ids` of the last batch is kept in `last_h_card_ids`."""
 
-  _state_keys = STATE_KEYS
-  _action_keys = ACTION_KEYS
-
-  def __init__(self, spec: _YGOProEnvSpec):
+  def __init__(self, spec):
     if _MODULE["engine_factory"] is None:
       raise RuntimeError(
         "YGOPro-v0: the duel engine (ygopro-core, Lua, SQLite card database) is not part of envpool_amd; "
         "call envpool_amd.ygopro.init_module(engine_factory, card_table) first (the reference's init_module "
         "plays the same role), or encode states of your own engine with envpool_amd.ygopro.YGOProEncoder")
     from .. import capi_ygo
-    self._spec = spec
-    c = dict(zip(CONFIG_KEYS, spec._config_values))
     made = tuple(_MODULE["engine_factory"](spec))
     ctx, reset, step = made[:3]
-    self._owner = made[3:] or None
-    engine, self._keep = capi_ygo.make_engine(ctx, reset, step)
+    engine, keep = capi_ygo.make_engine(ctx, reset, step)
     table = _MODULE["card_table"]
     if not isinstance(table, C.Array):
       rows = list(table)
@@ -182,38 +148,22 @@ class _YGOProEnvPool:
       for i, r in enumerate(rows):
         tab[i] = capi_ygo.CardData(*[int(v) for v in r], 0)
       table = tab
-    cfg = capi_ygo.default_config(
-      max_cards=c["max_cards"], max_options=c["max_options"], n_history_actions=c["n_history_actions"],
-      max_multi_select=c["max_multi_select"], max_episode_steps=c["max_episode_steps"],
-      device_id=_MODULE["device_id"], ring_depth=0, max_batch=c["batch_size"])
-    self._pool = capi_ygo.YgoPoolC(cfg, engine, c["num_envs"], c["batch_size"], table, len(table),
-                                   num_threads=c["num_threads"], thread_affinity_offset=c["thread_affinity_offset"])
+    super().__init__(spec, (engine.ctx or 0, engine.reset, engine.step), table, _MODULE["device_id"],
+                     _MODULE["env_id_offset"], (keep, made[3:], table))
     self.last_h_card_ids = None
 
-  def close(self) -> None:
-    self._pool.close()
-
-  def _send(self, action: List[np.ndarray]) -> None:
-    # _action_keys order: env_id, players.env_id, action (env_spec.h:31-35, ygopro.h:1203-1207)
-    self._pool.send(action[0], action[2])
-
-  def _reset(self, env_ids: np.ndarray) -> None:
-    self._pool.reset(env_ids)
-
   def _recv(self) -> List[np.ndarray]:
-    from .. import capi
-    out = self._pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
-    self.last_h_card_ids = out[16]
-    return out[:16]
+    arrays, _err = self._recv_all()  # (_err: a state the reference throws on; its row is an empty observation)
+    self.last_h_card_ids = arrays[16]
+    return arrays[:16]
 
   def _recv_device(self):
     """Additive: the next batch as device views (descriptors for envpool_amd.interop.as_torch): the
     policy that consumes the observations lives on the GPU, the actions it picks go back through
     `_send` as host arrays (the duel engine is on the host)."""
-    from .. import capi
-    descs, rows = self._pool.recv_device(allow=(capi.EP_ERR_ACTION_CHECK,))
+    descs, rows, prows = self._recv_device_all()
     self.last_h_card_ids = descs[16]
-    return descs[:16], rows, rows
+    return descs[:16], rows, prows
 
 
 from ..python.api import py_env, raw_env  # noqa: E402
