@@ -127,8 +127,12 @@ def main():
   dev_index = 0 if rehearse else local_rank
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
+  # EP_BENCH_FORCE_DIST=1: take the N>1 code path (process group, RCCL stat exchange on a side
+  # stream, node barrier, shard legs) with whatever world size there is - with ONE rank it runs real
+  # RCCL on a one-GPU box. For checking the code path; the figures of such a run are not a bench line.
+  dist_on = world > 1 or os.environ.get("EP_BENCH_FORCE_DIST") == "1"
   node_barrier = None
-  if world > 1:
+  if dist_on:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # gloo carries everything that lives on the host (timings, the barrier's set-up); RCCL carries
     # the one device-side exchange there is, the episode-stat all-gather
@@ -142,7 +146,7 @@ def main():
     # EP_BENCH_BARRIER=dist restores dist.barrier(). Device first, then ranks: when the barrier
     # falls, every rank's GPU is idle (opening side) / has finished its K steps (closing side).
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
       if os.environ.get("EP_BENCH_BARRIER") == "dist":
         dist.barrier()
       else:
@@ -169,7 +173,7 @@ def main():
   batches = (capi.Batch * T)()
 
   # episode-stat exchange buffers (multi-GPU only)
-  if world > 1:
+  if dist_on:
     st_ret = torch.zeros(N, dtype=torch.float32, device=dev)
     st_len = torch.zeros(N, dtype=torch.int32, device=dev)
     g_ret = torch.zeros(world * N, dtype=torch.float32, device=dev)
@@ -189,7 +193,7 @@ def main():
   exch = {"since": 0, "count": 0,
           "via": "host+gloo (rehearsal)" if rehearse and not rehearse_real_init else "RCCL all_gather_into_tensor",
           "in_run": 0}
-  side = torch.cuda.Stream(device=dev) if world > 1 else None
+  side = torch.cuda.Stream(device=dev) if dist_on else None
 
   def exchange_stats_now():
     with torch.cuda.stream(side):
@@ -209,13 +213,13 @@ def main():
     exch["in_run"] += 1
 
   def exchange_stats(steps_done):
-    if world > 1:
+    if dist_on:
       exch["since"] += steps_done
       if exch["since"] >= STATS_EVERY:
         exch["since"] = 0
         exchange_stats_now()
 
-  if world > 1:
+  if dist_on:
     # first exchange, untimed: RCCL connects here. Should it fail on this machine, the gather falls
     # back to host memory + gloo on every rank alike and the line says so.
     failed = 0
@@ -301,7 +305,7 @@ def main():
     if breakdown and rank == 0:
       print(f"[breakdown] run {r}: wall {1e6 * (t1 - t0):.1f} us, kernel {tot.value:.1f} us in {cnt.value} launches, "
             + ", ".join(f"{k} {v:.1f}" for k, v in phases.items()), file=sys.stderr, flush=True)
-  if world > 1:
+  if dist_on:
     tmax = torch.tensor(walls, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     walls = [float(x) for x in tmax.tolist()]
@@ -376,7 +380,7 @@ def main():
 
   # multi-player pools (ragged player dimension): 3 players max, every env sent back each step with
   # one action row per player it reported (the previous batch's info:players.env_id, a device view)
-  if rank == 0 and world == 1:
+  if rank == 0 and not dist_on:
     try:
       mp = capi.DummyPoolC(num_envs=N, seed=SEED, device_id=dev_index, max_num_players=3, ring_depth=4)
       hm = mp.handle
@@ -415,7 +419,7 @@ def main():
 
   # the boundary also takes host buffers (the reference's numpy path): PCIe-inclusive rate,
   # host actions in, host StateBuffer out, one launch per step. Reported, never `value`.
-  if rank == 0 and world == 1:
+  if rank == 0 and not dist_on:
     import numpy as np
     hk = 64
     h_env = np.arange(N, dtype=np.int32)
@@ -438,7 +442,7 @@ def main():
               "kernels read the pinned staging area and write the pinned result block over PCIe themselves"}
 
   cpu = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and not dist_on and not args.no_cpu_baseline:
     from oracle.dummy_oracle import DummyOracle, bench_sync_mt, bench_sync_threadpool
     o = DummyOracle(num_envs=N, seed=SEED)
     c0 = time.perf_counter()
@@ -492,7 +496,7 @@ def main():
   # shape: 1024 records per step through the pinned pipeline; plus a 65536-record device-resident
   # batch for the encode kernel's own roofline figure). Reported next to the headline value.
   ygo = None
-  if rank == 0 and world == 1 and not args.no_ygo:
+  if rank == 0 and not dist_on and not args.no_ygo:
     try:
       from tools import bench_ygo
       r = bench_ygo.run(cpu_seconds=0.0 if args.no_cpu_baseline else 5.0)
@@ -527,7 +531,7 @@ def main():
           ygo["roofline"]["traffic"] = t * big["records_per_launch"]
     except Exception as ex:  # the headline line must still be printed
       ygo = {"error": repr(ex)}
-  elif world > 1 and not args.no_ygo:
+  elif dist_on and not args.no_ygo:
     # N > 1: every rank encodes its own shard of envs (no exchange on this path either); the
     # aggregate is all ranks' records over the slowest rank's time
     try:
@@ -577,7 +581,7 @@ def main():
       "ms_per_step_all_runs": [w / K * 1e3 for w in walls],
       **({"stats_exchanges_in_each_run": exch_in_run, "stats_exchanges_in_median_run": exch_in_run[med],
           "stats_exchanges_total": exch["count"],
-          "barrier": os.environ.get("EP_BENCH_BARRIER", "shared-memory generation barrier (one node)")} if world > 1 else {}),
+          "barrier": os.environ.get("EP_BENCH_BARRIER", "shared-memory generation barrier (one node)")} if dist_on else {}),
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
       "data": "synthetic",
       "config": {
@@ -585,7 +589,7 @@ def main():
                     f"fused rollout T={T} steps/launch, device-resident actions, StateBuffer ring depth {2 * T}",
         "global_num_envs": world * N, "sharding": "env_id blocks, one independent pool per GPU",
         "collective": (f"all-gather of episode (return,length), {N * 8} B per rank, every {STATS_EVERY} steps on a side "
-                       f"stream, via {exch['via']}") if world > 1 else "none",
+                       f"stream, via {exch['via']}") if dist_on else "none",
       },
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -602,7 +606,7 @@ def main():
     print(json.dumps(line), flush=True)
 
   pool.close()
-  if world > 1:
+  if dist_on:
     node_barrier.close()
     dist.destroy_process_group()
 
