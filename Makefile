@@ -41,6 +41,13 @@ synth: tools/libygosynth.so
 tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpool_amd.h
 	gcc -O2 -fPIC -shared -std=gnu11 -Wall -pthread -o $@ $<
 
+# Diagnostic programs (launch floors, host-side latencies of the step loop). Not part of `all`.
+diag: tools/launch_floor tools/host_latency
+tools/launch_floor: tools/launch_floor.cpp
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
+tools/host_latency: tools/host_latency.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
+
 # Host-code sanitizer target (GPU sanitizers are not available on this pool): the library's host
 # code under ASan + UBSan, driven by tools/sanitize_host.cpp on the CPU. Not part of `all`.
 CLANG ?= /opt/rocm/lib/llvm/bin/clang
@@ -61,4 +68,4 @@ clean:
 	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib pymod oracle synth sanitize clean
+.PHONY: all lib pymod oracle synth sanitize diag clean
