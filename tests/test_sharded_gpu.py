@@ -126,3 +126,79 @@ def test_two_ranks_step_product_pools_and_gather_stats(tmp_path):
      "--master-port", "29537", str(script)], env=env, capture_output=True, text=True, timeout=240)
   assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
   assert out.stdout.count("ok") == 2
+
+
+_YGO_WORKER = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.environ["EP_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from envpool_amd import capi, capi_ygo
+from envpool_amd.shard import shard_range
+from oracle import ygo_oracle
+from tools import ygo_synth
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+G, B = 512, 128                               # config 5's shape scaled down: G envs over `world` pools, async batches
+off, n = shard_range(rank, world, G)
+cfg = capi_ygo.default_config(max_batch=B, ring_depth=0, device_id=0)
+table = ygo_synth.make_table(1000, seed=0)
+eng = ygo_synth.SynthEngine(cfg, table, n, seed=3 + rank)
+eng.set_env_id_offset(off)
+model = ygo_synth.EnginePoolModel(cfg, table, n, seed=3 + rank)
+pool = capi_ygo.YgoPoolC(cfg, eng.engine(), n, B, table, len(table), num_threads=3)
+pool.set_env_id_offset(off)
+pool.set_recv_timeout(30000)
+ids = np.arange(off, off + n, dtype=np.int32)
+pool.reset(ids)
+expect = {int(e): model.advance(int(e) - off) for e in ids}
+seen = []
+checked = 0
+for it in range(6):
+  out = pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+  got = out[0]
+  assert ((got >= off) & (got < off + n)).all()
+  raws = [expect.pop(int(e)) for e in got]
+  arr = (capi_ygo.RawState * len(raws))()
+  for i, (r, e) in enumerate(zip(raws, got)):
+    C.memmove(C.byref(arr[i]), C.byref(r), C.sizeof(capi_ygo.RawState))
+    arr[i].env_id = int(e)
+  want, status = ygo_oracle.write_batch(cfg, table, arr, len(raws))
+  for j in range(len(raws)):
+    if status[j] == 0:
+      assert all(np.asarray(out[k][j]).tobytes() == np.asarray(want[k][j]).tobytes() for k in range(17)), (rank, it, j)
+      checked += 1
+  seen.append(got.copy())
+  act = (got % 7).astype(np.int32)
+  pool.send(got, act)
+  for e, a in zip(got, act):
+    expect[int(e)] = model.advance(int(e) - off, int(a))
+assert checked > 0.9 * 6 * B
+# the ids every rank received, gathered: the union is the global id range, each shard its own block
+mine = torch.from_numpy(np.unique(np.concatenate(seen)).astype(np.int64))
+cnt = torch.tensor([mine.numel()])
+cnts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(cnts, cnt)
+pad = torch.full((max(int(c) for c in cnts),), -1, dtype=torch.int64); pad[:mine.numel()] = mine
+parts = [torch.zeros_like(pad) for _ in range(world)]
+dist.all_gather(parts, pad)
+allids = np.concatenate([p.numpy()[p.numpy() >= 0] for p in parts])
+assert len(set(allids.tolist())) == len(allids) and allids.min() >= 0 and allids.max() < G
+pool.close(); eng.close()
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_ranks_ygopro_pools_over_sharded_ids(tmp_path):
+  """Config 5's multi-GPU shape with the product in it: two ranks (gloo; both on cuda:0 of this
+  one-GPU box) each run an async ep_ygo_pool over their block of GLOBAL env ids
+  (ep_ygo_pool_set_env_id_offset); every row is checked against the oracle, and the ids the ranks
+  received partition the global range."""
+  script = tmp_path / "worker.py"
+  script.write_text(_YGO_WORKER)
+  env = dict(os.environ, EP_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+  out = subprocess.run(
+    [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+     "--master-port", "29539", str(script)], env=env, capture_output=True, text=True, timeout=240)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  assert out.stdout.count("ok") == 2
