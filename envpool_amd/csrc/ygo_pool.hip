@@ -24,6 +24,8 @@
 #include <sched.h>
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -166,6 +168,40 @@ void worker_loop(ep_ygo_pool* p) {  // async_envpool.h:117-128
   }
 }
 
+// std::thread::hardware_concurrency() (what async_envpool.h:103,114 uses) counts the machine's CPUs;
+// a job confined by its affinity mask or by a cgroup CPU quota (a container, one GPU's share of a
+// node) would start several workers per CPU it may actually use, and they spin before they sleep.
+unsigned usable_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int c = CPU_COUNT(&set);
+    if (c > 0) n = std::min<unsigned>(n, (unsigned)c);
+  }
+  auto quota = [](const char* path, bool v2) -> double {
+    FILE* f = fopen(path, "r");
+    if (!f) return 0.0;
+    char a[64] = {0};
+    long long q = -1, per = 100000;
+    double cpus = 0.0;
+    if (v2) {
+      if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) cpus = (double)atoll(a) / (double)per;
+    } else if (fscanf(f, "%lld", &q) == 1 && q > 0) {
+      FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      if (g) { if (fscanf(g, "%lld", &per) != 1) per = 100000; fclose(g); }
+      if (per > 0) cpus = (double)q / (double)per;
+    }
+    fclose(f);
+    return cpus;
+  };
+  double lim = quota("/sys/fs/cgroup/cpu.max", true);
+  if (lim <= 0.0) lim = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+  if (lim >= 1.0) n = std::min<unsigned>(n, (unsigned)(lim + 0.5));
+  if (const char* e = getenv("EP_YGO_POOL_THREADS")) { const int v = atoi(e); if (v > 0) n = (unsigned)v; }
+  return std::max(1u, n);
+}
+
 int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* action, bool force_reset) {
   if (!p || (n > 0 && !env_id) || (n > 0 && !force_reset && !action)) return fail(EP_ERR_INVALID, "null argument");
   if (n < 0 || n > p->N) return fail(EP_ERR_TOO_LARGE, "n = %d outside [0, num_envs = %d]", n, p->N);
@@ -240,8 +276,7 @@ int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, in
   }
   p->envs.reset(new EnvSlot[(size_t)num_envs]);
   p->stamp.assign((size_t)num_envs, 0u);
-  unsigned hw = std::thread::hardware_concurrency();
-  if (hw == 0) hw = 1;
+  const unsigned hw = usable_cpus();
   if (num_threads <= 0) num_threads = (int32_t)std::min<unsigned>((unsigned)p->B, hw);  // async_envpool.h:113-115
   p->workers.reserve((size_t)num_threads);
   for (int t = 0; t < num_threads; ++t) {
@@ -249,7 +284,7 @@ int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, in
     if (thread_affinity_offset >= 0) {  // async_envpool.h:130-141
       cpu_set_t set;
       CPU_ZERO(&set);
-      CPU_SET(((unsigned)thread_affinity_offset + (unsigned)t) % hw, &set);
+      CPU_SET(((unsigned)thread_affinity_offset + (unsigned)t) % std::max(1u, std::thread::hardware_concurrency()), &set);
       (void)pthread_setaffinity_np(p->workers.back().native_handle(), sizeof(set), &set);
     }
   }
