@@ -10,7 +10,7 @@ EP_U16 = 6
 YGO_STATE_KEYS = [
   "info:env_id", "info:players.env_id", "elapsed_step", "done", "reward", "discount", "step_type", "trunc",
   "obs:cards_", "obs:global_", "obs:actions_", "obs:h_actions_", "info:num_options", "info:to_play",
-  "info:is_selfplay", "info:win_reason", "aux:h_card_ids",
+  "info:is_selfplay", "info:win_reason", "aux:h_card_ids", "aux:action_mask",
 ]
 
 capi._NP[EP_U16] = np.uint16

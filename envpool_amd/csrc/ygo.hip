@@ -65,7 +65,7 @@ struct Slot {
   bool busy = false;
 };
 
-constexpr int kNumKeys = 17;
+constexpr int kNumKeys = 18;  // the reference's 16 state keys + aux:h_card_ids + aux:action_mask
 
 }  // namespace
 
@@ -132,6 +132,7 @@ void out_ptrs(ep_ygo_encoder* e, char* base, ygk::Outs* o) {
   o->is_selfplay = (int32_t*)(base + e->key_off[14]);
   o->win_reason = (int32_t*)(base + e->key_off[15]);
   o->h_card_ids = (uint16_t*)(base + e->key_off[16]);
+  o->action_mask = (uint8_t*)(base + e->key_off[17]);
 }
 
 int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot, bool lean_fetch = false, hipStream_t st = nullptr,
@@ -211,6 +212,7 @@ int describe(ep_ygo_encoder* e, int slot, int32_t mem_out, ep_batch* out) {
   set3(10, c.max_options, e->lay.nf);
   set3(11, c.n_history_actions, e->lay.nf);
   set3(16, c.max_options, c.max_multi_select);
+  out->arrays[17].ndim = 2; out->arrays[17].shape[1] = c.max_options;
   return EP_OK;
 }
 
@@ -261,9 +263,9 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   const int nf = e->lay.nf;
   const size_t rowb[kNumKeys] = {4, 4, 4, 1, 4, 4, 4, 1, (size_t)2 * cfg->max_cards * EP_YGO_CARD_FEATS, 8,
                                  (size_t)cfg->max_options * nf, (size_t)cfg->n_history_actions * nf, 4, 4, 4, 4,
-                                 (size_t)cfg->max_options * cfg->max_multi_select * 2};
+                                 (size_t)cfg->max_options * cfg->max_multi_select * 2, (size_t)cfg->max_options};
   const int dt[kNumKeys] = {EP_I32, EP_I32, EP_I32, EP_BOOL, EP_F32, EP_F32, EP_I32, EP_BOOL, EP_U8, EP_U8,
-                            EP_U8, EP_U8, EP_I32, EP_I32, EP_I32, EP_I32, EP_U16};
+                            EP_U8, EP_U8, EP_I32, EP_I32, EP_I32, EP_I32, EP_U16, EP_BOOL};
   size_t off = 0;
   for (int k = 0; k < kNumKeys; ++k) {
     e->key_off[k] = off;

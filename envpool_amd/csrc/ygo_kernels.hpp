@@ -53,6 +53,7 @@ struct Outs {
   int32_t* env_id; int32_t* penv; int32_t* elapsed; uint8_t* done; float* reward; float* discount;
   int32_t* step_type; uint8_t* trunc; uint8_t* cards; uint8_t* global; uint8_t* actions; uint8_t* h_actions;
   int32_t* num_options; int32_t* to_play; int32_t* is_selfplay; int32_t* win_reason; uint16_t* h_card_ids;
+  uint8_t* action_mask;  // additive: [n, max_options] bool, arange(max_options) < info:num_options
 };
 
 __host__ __device__ inline int al16(int x) { return (x + 15) & ~15; }
@@ -624,6 +625,14 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
         put(ka->out.is_selfplay, o4, (int)(w[1] & 0xff));
         put(ka->out.win_reason, o4, (int)w[7]);
         put(ka->out.global, o8, make_uint2(glob0, glob1));
+      }
+      // the legal-action mask the reference leaves implicit (row i of obs:actions_ is an option iff
+      // i < info:num_options): one byte per option slot, lanes 0..max_options-1
+      if (!(YGO_SKIP & 2048)) {
+        KArgs ka = late_args();
+        const int shown = no_options ? 1 : n_opt;
+        uint8_t* const mrow = ka->out.action_mask + (int64_t)e * ka->max_options;
+        for (int k = lane; k < ka->max_options; k += 64) mrow[k] = (uint8_t)(k < shown);
       }
 
 

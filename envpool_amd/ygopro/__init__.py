@@ -90,7 +90,7 @@ class YGOProEncoder:
     from .. import capi
     out = self._enc.featurize(np.ascontiguousarray(records), allow=() if strict else (capi.EP_ERR_ACTION_CHECK,))
     d = dict(zip(self._capi.YGO_STATE_KEYS, out))
-    d["mask"] = np.arange(self.cfg.max_options, dtype=np.int32)[None, :] < d["info:num_options"][:, None]
+    d["mask"] = d["aux:action_mask"]
     return d
 
   def submit(self, records: np.ndarray) -> None:
@@ -100,7 +100,7 @@ class YGOProEncoder:
     from .. import capi
     out = self._enc.collect(allow=() if strict else (capi.EP_ERR_ACTION_CHECK,))
     d = dict(zip(self._capi.YGO_STATE_KEYS, out))
-    d["mask"] = np.arange(self.cfg.max_options, dtype=np.int32)[None, :] < d["info:num_options"][:, None]
+    d["mask"] = d["aux:action_mask"]
     return d
 
 
@@ -150,11 +150,11 @@ class _YGOProEnvPool(_YGOProNativePool):
       table = tab
     super().__init__(spec, (engine.ctx or 0, engine.reset, engine.step), table, _MODULE["device_id"],
                      _MODULE["env_id_offset"], (keep, made[3:], table))
-    self.last_h_card_ids = None
+    self.last_h_card_ids = self.last_action_mask = None
 
   def _recv(self) -> List[np.ndarray]:
     arrays, _err = self._recv_all()  # (_err: a state the reference throws on; its row is an empty observation)
-    self.last_h_card_ids = arrays[16]
+    self.last_h_card_ids, self.last_action_mask = arrays[16], arrays[17]
     return arrays[:16]
 
   def _recv_device(self):
@@ -162,7 +162,7 @@ class _YGOProEnvPool(_YGOProNativePool):
     policy that consumes the observations lives on the GPU, the actions it picks go back through
     `_send` as host arrays (the duel engine is on the host)."""
     descs, rows, prows = self._recv_device_all()
-    self.last_h_card_ids = descs[16]
+    self.last_h_card_ids, self.last_action_mask = descs[16], descs[17]
     return descs[:16], rows, prows
 
 

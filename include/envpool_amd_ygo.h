@@ -140,9 +140,11 @@ int32_t ep_ygo_action_feats(const ep_ygo_config* cfg);
  * `n` records. `records` is host (pageable or pinned) or device memory per `mem_in`; the
  * result is described in `out` as in ep_pool_recv, keys in the reference's `_state_keys`
  * order (8 common keys, then obs:cards_, obs:global_, obs:actions_, obs:h_actions_,
- * info:num_options, info:to_play, info:is_selfplay, info:win_reason) followed by one
- * additive key: aux:h_card_ids uint16 [n, max_options, max_multi_select] (the
- * back-derivation of :1863-1879, so the host ring update needs no GPU read-back of obs).
+ * info:num_options, info:to_play, info:is_selfplay, info:win_reason) followed by two
+ * additive keys: aux:h_card_ids uint16 [n, max_options, max_multi_select] (the
+ * back-derivation of :1863-1879, so the host ring update needs no GPU read-back of obs) and
+ * aux:action_mask bool [n, max_options], the legal-action mask the reference leaves implicit
+ * (row i of obs:actions_ is an option iff i < info:num_options).
  * Blocking. Submit and collect as ONE operation: refused with EP_ERR_INVALID while batches of
  * ep_ygo_submit / ep_ygo_commit_slot are in flight (it returns the batch it was given, not the
  * oldest one). Returns EP_ERR_ACTION_CHECK when a record tripped a condition on which the

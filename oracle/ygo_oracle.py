@@ -35,6 +35,9 @@ def write_batch(cfg, table, raw_states, n):
   L.yo_write_batch(C.byref(cfg), table, len(table), raw_states, n, *[o.ctypes.data for o in outs], status.ctypes.data)
   outs[3] = outs[3].view(np.bool_)
   outs[7] = outs[7].view(np.bool_)
+  # the additive aux:action_mask key is, by definition, the mask the reference leaves implicit:
+  # row i of obs:actions_ is an option iff i < info:num_options
+  outs.append(np.arange(cfg.max_options, dtype=np.int32)[None, :] < outs[12][:, None])
   return [o[:n] for o in outs], status[:n]
 
 

@@ -165,7 +165,7 @@ for it in range(6):
   want, status = ygo_oracle.write_batch(cfg, table, arr, len(raws))
   for j in range(len(raws)):
     if status[j] == 0:
-      assert all(np.asarray(out[k][j]).tobytes() == np.asarray(want[k][j]).tobytes() for k in range(17)), (rank, it, j)
+      assert all(np.asarray(out[k][j]).tobytes() == np.asarray(want[k][j]).tobytes() for k in range(18)), (rank, it, j)
       checked += 1
   seen.append(got.copy())
   act = (got % 7).astype(np.int32)

@@ -254,7 +254,7 @@ def test_python_front_end_and_action_mask():
   recs, est = capi_ygo.emit_records(enc.cfg, sb.raw, n)
   out = enc.encode(recs, strict=False)
   keys = list(out)
-  assert keys[:16] == list(spec._state_keys) and keys[16:] == ["aux:h_card_ids", "mask"]
+  assert keys[:16] == list(spec._state_keys) and keys[16:] == ["aux:h_card_ids", "aux:action_mask", "mask"]
   ok = np.nonzero((status == 0) & (est == 0))[0]
   _compare([out[k] for k in capi_ygo.YGO_STATE_KEYS], want, ok, "front end")
   acts = out["obs:actions_"][ok]

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from envpool_amd import capi, capi_ygo  # noqa: E402
 
-NK = 17  # 16 state keys + aux:h_card_ids
+NK = 18  # 16 state keys + aux:h_card_ids + aux:action_mask
 
 
 def _expect_rows(cfg, table, raws):

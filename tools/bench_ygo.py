@@ -40,7 +40,7 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
   read_b = 64 + cfg.n_history_actions * nf + listed * 16 + n_opt * (12 + 4 * cfg.max_multi_select)
   read_b = np.where(hdr[:, 3] == 0, 64, read_b)
   write_b = 2 * cfg.max_cards * 39 + 8 + cfg.max_options * nf + cfg.n_history_actions * nf + 4 * 4 + (4 + 4 + 4 + 1 + 4 + 4 + 4 + 1) \
-      + cfg.max_options * cfg.max_multi_select * 2
+      + cfg.max_options * cfg.max_multi_select * 2 + cfg.max_options  # (+ aux:h_card_ids, aux:action_mask)
   alg_per_rec = float(read_b.mean() + write_b)
 
   enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
