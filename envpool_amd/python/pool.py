@@ -127,7 +127,16 @@ class EnvPoolFrontEnd:
     self._send(arrays)
 
   def recv(self, reset: bool = False, return_info: bool = True):
-    return self._to(self._recv(), reset, return_info)
+    return self._with_mask(self._to(self._recv(), reset, return_info))
+
+  def _with_mask(self, result, to_torch=None):
+    """Pools whose raw class keeps an explicit legal-action mask of the last batch
+    (`last_action_mask`, YGOPro: arange(max_options) < info:num_options, written by the encode
+    kernel) hand it out as info["action_mask"] (additive; the dm flavour has no info dict)."""
+    mask = getattr(self, "last_action_mask", None)
+    if mask is not None and isinstance(result, tuple) and isinstance(result[-1], dict):
+      result[-1]["action_mask"] = to_torch(mask) if to_torch else mask
+    return result
 
   def async_reset(self) -> None:
     self._reset(self.all_env_ids)
@@ -182,7 +191,8 @@ class EnvPoolFrontEnd:
     if not hasattr(self, "_recv_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
     descs, _, _ = self._recv_device()
-    return self._torch_out(descs, reset)
+    from ..interop import as_torch
+    return self._with_mask(self._torch_out(descs, reset), lambda d: as_torch(d, self._torch_dev))
 
   def step_torch(self, action, env_id=None):
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action

@@ -211,6 +211,11 @@ def test_make_ygopro_with_init_module():
     obs_t, rew_t, term_t, trunc_t, info_t = env.recv_torch()
     assert obs_t["cards_"].is_cuda and tuple(obs_t["cards_"].shape) == (N, 150, 39)
     assert (info_t["win_reason"] == 3).all().item() and info_t["env_id"].cpu().tolist() == list(range(N))
+    m = info_t["action_mask"]
+    assert m.is_cuda and tuple(m.shape) == (N, 16)
+    assert (m.sum(1).cpu() == info_t["num_options"].cpu().clamp(max=16)).all()
+    obs, rew, term, trunc, info = env.step(np.zeros(N, np.int32))
+    assert info["action_mask"].shape == (N, 16) and (info["action_mask"].sum(1) == np.minimum(info["num_options"], 16)).all()
     env.close()
   finally:
     ygopro.init_module(None, None)
