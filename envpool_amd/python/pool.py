@@ -106,6 +106,10 @@ class EnvPoolFrontEnd:
 
   def _from(self, action, env_id: Optional[np.ndarray] = None) -> List[np.ndarray]:
     keys = self._spec._action_keys
+    if hasattr(action, "detach") and hasattr(action, "cpu"):
+      action = action.detach().cpu().numpy()  # a torch tensor (e.g. a GPU policy's choice): the pool's inputs are host arrays
+    if env_id is not None and hasattr(env_id, "detach") and hasattr(env_id, "cpu"):
+      env_id = env_id.detach().cpu().numpy()
     if isinstance(action, dict):
       adict = _flatten_action(action)
     else:

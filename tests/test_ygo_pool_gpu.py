@@ -214,7 +214,8 @@ def test_make_ygopro_with_init_module():
     m = info_t["action_mask"]
     assert m.is_cuda and tuple(m.shape) == (N, 16)
     assert (m.sum(1).cpu() == info_t["num_options"].cpu().clamp(max=16)).all()
-    obs, rew, term, trunc, info = env.step(np.zeros(N, np.int32))
+    import torch
+    obs, rew, term, trunc, info = env.step(torch.zeros(N, dtype=torch.int32, device="cuda"), env_id=info_t["env_id"])
     assert info["action_mask"].shape == (N, 16) and (info["action_mask"].sum(1) == np.minimum(info["num_options"], 16)).all()
     env.close()
   finally:
