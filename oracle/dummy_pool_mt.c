@@ -41,13 +41,13 @@
 
 /* ---- LightweightSemaphore: spin, then futex ------------------------------------------- */
 typedef struct {
-  _Atomic int32_t count;
-  _Atomic int32_t waiters;
+  _Atomic int32_t count; /* > 0: signals available; < 0: that many threads are (about to be) asleep */
+  _Atomic int32_t wake;  /* wake-ups handed to sleepers, the futex word */
 } lsem;
 
 static void lsem_init(lsem* s, int initial) {
   atomic_store(&s->count, initial);
-  atomic_store(&s->waiters, 0);
+  atomic_store(&s->wake, 0);
 }
 
 static inline int lsem_try(lsem* s) {
@@ -64,17 +64,26 @@ static void lsem_wait(lsem* s) {
     if (lsem_try(s)) return;
     __builtin_ia32_pause();
   }
-  for (;;) {
-    if (lsem_try(s)) return;
-    atomic_fetch_add(&s->waiters, 1);
-    syscall(SYS_futex, &s->count, FUTEX_WAIT_PRIVATE, 0, NULL, NULL, 0);
-    atomic_fetch_sub(&s->waiters, 1);
+  if (atomic_fetch_sub_explicit(&s->count, 1, memory_order_acquire) > 0) return;
+  for (;;) { /* registered as a sleeper: wait for a wake-up addressed to sleepers */
+    int32_t w = atomic_load_explicit(&s->wake, memory_order_acquire);
+    while (w > 0)
+      if (atomic_compare_exchange_weak_explicit(&s->wake, &w, w - 1, memory_order_acquire, memory_order_relaxed)) return;
+    syscall(SYS_futex, &s->wake, FUTEX_WAIT_PRIVATE, 0, NULL, NULL, 0);
   }
 }
 
+/* The signaller touches the semaphore's memory for the last time in the fetch_add unless a thread
+ * is registered as asleep (count was negative): the consumer frees a StateBuffer, semaphore
+ * included, as soon as its wait returns (state_buffer_queue.h:148), so a signaller that looked at
+ * the object again after making the count positive would read freed memory (ThreadSanitizer found
+ * exactly that in this file's first version). */
 static void lsem_signal(lsem* s, int n) {
-  atomic_fetch_add_explicit(&s->count, n, memory_order_release);
-  if (atomic_load(&s->waiters) > 0) syscall(SYS_futex, &s->count, FUTEX_WAKE_PRIVATE, n, NULL, NULL, 0);
+  const int32_t old = atomic_fetch_add_explicit(&s->count, n, memory_order_release);
+  if (old >= 0) return;
+  const int32_t to_release = -old < n ? -old : n;
+  atomic_fetch_add_explicit(&s->wake, to_release, memory_order_release);
+  syscall(SYS_futex, &s->wake, FUTEX_WAKE_PRIVATE, to_release, NULL, NULL, 0);
 }
 
 /* ---- ActionBufferQueue (action_buffer_queue.h:35-85) ------------------------------------ */
