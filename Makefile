@@ -7,6 +7,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 PYTHON ?= python3
 ARCH ?= gfx950
+CLANG ?= /opt/rocm/lib/llvm/bin/clang
 EXT := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
 PYINC := $(shell $(PYTHON) -m pybind11 --includes)
 
@@ -48,9 +49,17 @@ tools/launch_floor: tools/launch_floor.cpp
 tools/host_latency: tools/host_latency.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
 
+# ThreadSanitizer over the host logic of ep_ygo_pool (ygo_pool.hip compiled as plain host C++
+# against a mock encoder: TSan and the ROCm runtime do not coexist). Not part of `all`.
+tsan-pool: build/tsan_ygo_pool
+	TSAN_OPTIONS=halt_on_error=1 build/tsan_ygo_pool
+build/tsan_ygo_pool: tools/tsan_ygo_pool.cpp $(CSRC)/ygo_pool.hip $(CSRC)/common.hpp include/envpool_amd_ygo.h include/envpool_amd.h
+	mkdir -p build
+	$(CLANG)++ -std=c++17 -O1 -g -fsanitize=thread -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude \
+	  -o $@ tools/tsan_ygo_pool.cpp $(CSRC)/ygo_pool.hip -pthread
+
 # Host-code sanitizer target (GPU sanitizers are not available on this pool): the library's host
 # code under ASan + UBSan, driven by tools/sanitize_host.cpp on the CPU. Not part of `all`.
-CLANG ?= /opt/rocm/lib/llvm/bin/clang
 SANFLAGS := -fsanitize=address -fsanitize=undefined -fno-omit-frame-pointer
 sanitize: build/sanitize_host
 	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 build/sanitize_host
@@ -68,4 +77,4 @@ clean:
 	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib pymod oracle synth sanitize diag clean
+.PHONY: all lib pymod oracle synth sanitize tsan-pool diag clean
