@@ -338,3 +338,54 @@ def test_ep_pool_step_resident_server(n, steps):
   rc = L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b))
   assert rc in (capi.EP_ERR_ACTION_CHECK, 0)   # (0 when env 5 happened to be on its auto-reset step)
   g.close()
+
+
+@pytest.mark.parametrize("host_first", [True, False])
+def test_host_and_device_sends_into_one_batch(host_first):
+  """Host mode gives a batch a pinned result block when its first rows come from host memory, and
+  every later kernel that writes rows of that batch must write into the block too - a device-memory
+  send included; a batch begun by a device-memory send stays in the ring and a host recv copies it
+  out. Either way the batch equals the oracle's, and so does a device-view recv of a block-backed
+  batch (the block is copied into the ring first)."""
+  import torch
+
+  from envpool_amd import capi
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  N, B = 64, 16
+  g, o = _pair(num_envs=N, batch_size=B, seed=3, ring_depth=16)
+  ids = np.arange(N, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  for it in range(12):
+    got, want = g._recv(), o._recv()
+    assert_batches_equal(got, want, f"it {it}")
+    sel = np.asarray(want[0]).astype(np.int32)
+    halves = [sel[:B // 2], sel[B // 2:]]
+    for k, part in enumerate(halves):
+      from_host = (k == 0) == host_first
+      if from_host:
+        g._send(dummy_action(part))
+      else:
+        t_ids = torch.from_numpy(part.copy()).to(dev)
+        t_la = torch.full((len(part), 6), 1.5, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_ids.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr())
+        n = len(part)
+        capi._check(L.ep_pool_send(g.handle, 5, ptrs, (C.c_int64 * 5)(n, n, n, n, n), capi.EP_MEM_DEVICE))
+      o._send(dummy_action(part))
+  # a block-backed batch wanted as device views: send from host, receive on the device
+  for it in range(3):
+    b = capi.Batch()
+    capi._check(L.ep_pool_recv(g.handle, capi.EP_MEM_DEVICE, C.byref(b)))
+    want = o._recv()
+    assert b.num_rows == B
+    hip_ids = np.zeros(B, np.int32)
+    assert L.hipMemcpy(C.c_void_p(hip_ids.ctypes.data), C.c_void_p(b.arrays[0].data), C.c_size_t(4 * B), C.c_int(2)) == 0
+    hip_el = np.zeros(B, np.int32)
+    assert L.hipMemcpy(C.c_void_p(hip_el.ctypes.data), C.c_void_p(b.arrays[2].data), C.c_size_t(4 * B), C.c_int(2)) == 0
+    raw = np.zeros((B, 10), np.int32)
+    assert L.hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(b.arrays[8].data), C.c_size_t(40 * B), C.c_int(2)) == 0
+    assert hip_ids.tobytes() == want[0].tobytes() and hip_el.tobytes() == want[2].tobytes() and raw.tobytes() == want[8].tobytes()
+    sel = np.asarray(want[0]).astype(np.int32)
+    g._send(dummy_action(sel)); o._send(dummy_action(sel))
+  g.close()
