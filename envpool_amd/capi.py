@@ -185,6 +185,51 @@ class DummyPoolC:
     self.last_status = rc
     return out
 
+  # device-memory flavours of the two calls above, for tests and soaks: the arrays travel through
+  # plain hipMalloc'd memory (no torch needed), results come back as numpy copies of the views
+  def _send_via_device(self, action):
+    arrs = [np.ascontiguousarray(action[0], np.int32), np.ascontiguousarray(action[1], np.int32),
+            np.ascontiguousarray(action[2], np.float64), np.ascontiguousarray(action[3], np.int32),
+            np.ascontiguousarray(action[4], np.int32)]
+    L = self._L
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipFree.argtypes = [C.c_void_p]
+    dptr = []
+    for a in arrs:
+      d = C.c_void_p()
+      assert L.hipMalloc(C.byref(d), max(256, a.nbytes)) == 0
+      if a.nbytes:
+        assert L.hipMemcpy(d, a.ctypes.data, a.nbytes, 1) == 0  # host to device (synchronous)
+      dptr.append(d)
+    ptrs = (C.c_void_p * 5)(*[d.value for d in dptr])
+    dims = (C.c_int64 * 5)(*[a.shape[0] for a in arrs])
+    try:
+      _check(L.ep_pool_send(self._h, 5, ptrs, dims, EP_MEM_DEVICE))
+    finally:
+      _check(L.ep_pool_sync(self._h))  # the kernels have read the arrays: they can go
+      for d in dptr:
+        L.hipFree(d)
+
+  def _recv_via_device(self, allow=()):
+    L = self._L
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    b = Batch()
+    rc = _check(L.ep_pool_recv(self._h, EP_MEM_DEVICE, C.byref(b)), allow=allow)
+    self.last_status = rc
+    out = []
+    for k in range(b.num_keys):
+      a = b.arrays[k]
+      if a.dtype == EP_CONTAINER_I32:
+        out.append(None)
+        continue
+      shape = tuple(a.shape[i] for i in range(a.ndim))
+      h = np.zeros(shape, np.dtype(_NP[a.dtype]))
+      if h.nbytes:
+        assert L.hipMemcpy(h.ctypes.data, a.data, h.nbytes, 2) == 0  # device to host
+      out.append(h)
+    return out
+
   def sync(self):
     _check(self._L.ep_pool_sync(self._h))
 

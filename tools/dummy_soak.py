@@ -31,12 +31,23 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
     g.set_recv_timeout(0)
     o = DummyOracle(**{k: v for k, v in kw.items() if k != "ring_depth"})
     ids = np.arange(n, dtype=np.int32)
+    # SOAK_MIXED=1: sends and recvs alternate between host and device memory (a device-memory send
+    # may not repeat an env: it would be reported, not stepped twice)
+    mixed = os.environ.get("SOAK_MIXED") == "1"
+
+    def send(a):
+      if mixed and len(set(np.asarray(a[0]).tolist())) == len(a[0]) and rng.random() < 0.3:
+        g._send_via_device(a)
+      else:
+        g._send(a)
     g._reset(ids); o._reset(ids)
     outstanding = n
     steps = int(rng.integers(5, 40))
     for it in range(steps):
       while outstanding >= B:
-        got, want = g._recv(), o._recv()
+        # (a fifth of the batches are received as device views: a batch that host-memory sends
+        # put into a pinned block has to come back through the ring then)
+        got, want = (g._recv_via_device() if mixed and rng.random() < 0.2 else g._recv()), o._recv()
         assert_batches_equal(got, want, f"pool {kw} it {it}")
         outstanding -= B
         last_ids = np.asarray(want[0])
@@ -48,7 +59,7 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
           sel = np.concatenate([sel, rng.choice(sel, size=min(3, len(sel), n - len(sel)))]).astype(np.int32)
         penv = np.asarray(want[1]).astype(np.int32)
         a = dummy_action(sel, penv)
-        g._send(a); o._send(a)
+        send(a); o._send(a)
         outstanding += len(sel)
         steps_total += len(sel)
         continue
@@ -59,7 +70,14 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
         sel = rng.choice(last_ids, size=int(rng.integers(1, len(last_ids) + 1)), replace=True).astype(np.int32)
       penv = sel + (rng.random(len(sel)) < 0.1).astype(np.int32)
       a = dummy_action(sel, penv)
-      g._send(a); o._send(a)
+      if mixed and not sync and len(sel) > 1 and len(set(sel.tolist())) == len(sel) and rng.random() < 0.3:
+        # one send as two, the halves through different memories: both write rows of the same batch
+        h = len(sel) // 2
+        for part, dev_mem in ((slice(0, h), False), (slice(h, None), True)):
+          pa = [a[0][part], a[1][part], a[2][part], a[3][part], a[4][part]]
+          (g._send_via_device if dev_mem else g._send)(pa); o._send(pa)
+      else:
+        send(a); o._send(a)
       outstanding += len(sel)
       steps_total += len(sel)
     del g
