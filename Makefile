@@ -17,7 +17,7 @@ HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HIP_DEPS := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inl) $(wildcard include/*.h)
 PYMODS := envpool_amd/dummy/dummy_envpool$(EXT) $(if $(wildcard $(CSRC)/py_ygopro.cpp),envpool_amd/ygopro/ygopro_envpool$(EXT))
 
-all: lib pymod oracle synth
+all: lib pymod oracle synth examples
 
 lib: $(LIB)
 
@@ -43,6 +43,11 @@ tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpoo
 	gcc -O2 -fPIC -shared -std=gnu11 -Wall -pthread -o $@ $<
 
 # Diagnostic programs (launch floors, host-side latencies of the step loop). Not part of `all`.
+# the C ABI from plain C: gcc only, no HIP headers
+examples: examples/dummy_step_loop
+examples/dummy_step_loop: examples/dummy_step_loop.c include/envpool_amd.h $(LIB)
+	gcc -O2 -std=c11 -Wall -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
+
 diag: tools/launch_floor tools/host_latency
 tools/launch_floor: tools/launch_floor.cpp
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
@@ -77,4 +82,4 @@ clean:
 	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib pymod oracle synth sanitize tsan-pool diag clean
+.PHONY: all lib pymod oracle synth examples sanitize tsan-pool diag clean
