@@ -463,11 +463,21 @@ static int commit_slot_impl(ep_ygo_encoder* e, int32_t n, const uint32_t* offset
         return fail(EP_ERR_INVALID, "offsets[%d] = %u is misaligned or outside the %lld used bytes", i, offsets[i], (long long)used_bytes);
     // offset table + exactly the bytes in use: one copy-engine transfer, under the kernel of the batch before
     memcpy(s.h_tab, offsets, 4 * (size_t)n);
-    hipStream_t cs = (e->submit_idx & 1) ? e->copy_stream2 : e->copy_stream;
-    HIP_TRY(hipMemcpyAsync(s.d_tab, s.h_tab, e->tab_bytes + (size_t)used_bytes, hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipEventRecord(s.copied, cs));
-    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
-    if (int rc = launch(e, s.d_rec, n, si, false, st, (const uint32_t*)s.d_tab)) return rc;
+    static const int packed_in_place = getenv("EP_YGO_PACKED_IN_PLACE") ? atoi(getenv("EP_YGO_PACKED_IN_PLACE")) : -1;
+    if (e->zero_copy && (packed_in_place == 1 || (packed_in_place != 0 && e->submit_idx == e->collect_idx))) {
+      // nothing else is in flight to hide a copy behind (a sync pool: commit, then wait): the kernel
+      // reads the offset table and the used bytes from the pinned slot itself - one launch instead
+      // of copy + event + wait + launch, and the transfer starts with the kernel
+      void* dev_tab = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev_tab, s.h_tab, 0));
+      if (int rc = launch(e, (const char*)dev_tab + e->tab_bytes, n, si, /*lean_fetch=*/true, st, (const uint32_t*)dev_tab)) return rc;
+    } else {
+      hipStream_t cs = (e->submit_idx & 1) ? e->copy_stream2 : e->copy_stream;
+      HIP_TRY(hipMemcpyAsync(s.d_tab, s.h_tab, e->tab_bytes + (size_t)used_bytes, hipMemcpyHostToDevice, cs));
+      HIP_TRY(hipEventRecord(s.copied, cs));
+      HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+      if (int rc = launch(e, s.d_rec, n, si, false, st, (const uint32_t*)s.d_tab)) return rc;
+    }
   } else if (n > 0) {
     int rc;
     if (e->zero_copy) {

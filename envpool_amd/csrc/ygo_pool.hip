@@ -9,7 +9,9 @@
 // read (ygo_raw_state). Everything after that point is this library's: the record is emitted on
 // the worker thread, travels to the GPU in the encoder's pinned ring and is encoded there.
 //
-//   send / reset  -> action queue (action_buffer_queue.h:35-85) -> worker threads
+//   send / reset  -> action queue (action_buffer_queue.h:35-85) -> worker threads. The queue is a ring
+//                    of 2 * num_envs cells like the reference's; cells are claimed a few at a time
+//                    with one compare-and-swap on the head index (no lock on the way to an env-step)
 //   worker        -> engine callback -> ep_ygo_emit_record -> row of the batch being filled
 //                    async pools (batch_size < num_envs): rows in ARRIVAL order
 //                    (state_buffer_queue.h:114-128); sync pools: row = position in the sent
@@ -28,7 +30,6 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
-#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -43,9 +44,24 @@ namespace {
 
 struct Slice {  // ActionBufferQueue::ActionSlice (+ the action itself: YGOPro's is one int32)
   int32_t env_id, order, action;
-  bool force_reset, quit;
-  uint64_t batch;  // sync pools: which send this slice belongs to
+  bool force_reset;
 };
+
+// One cell of the action ring: a Slice as two words that are read while other threads may be
+// claiming it (a reader that loses the claim throws its copy away).
+struct Cell {
+  std::atomic<uint64_t> a{0}, b{0};
+  void put(const Slice& s) {
+    a.store((uint64_t)(uint32_t)s.env_id | (uint64_t)(uint32_t)s.action << 32, std::memory_order_relaxed);
+    b.store((uint64_t)(uint32_t)s.order | (uint64_t)(s.force_reset ? 1 : 0) << 32, std::memory_order_relaxed);
+  }
+  Slice get() const {
+    const uint64_t x = a.load(std::memory_order_relaxed), y = b.load(std::memory_order_relaxed);
+    return Slice{(int32_t)(uint32_t)x, (int32_t)(uint32_t)y, (int32_t)(uint32_t)(x >> 32), (y >> 32 & 1) != 0};
+  }
+};
+
+constexpr int kVisit = 8;  // most slices one visit to the queue takes
 
 struct EnvSlot {
   int32_t current_step = -1;  // Env::current_step_ (env.h:71)
@@ -66,105 +82,133 @@ struct ep_ygo_pool {
   std::unique_ptr<EnvSlot[]> envs;
   std::vector<uint32_t> stamp;  // duplicate check of one send
   uint32_t stamp_val = 0;
-  // action queue
-  std::mutex qmu;
+  // action queue: cells [q_head, q_tail) are waiting. At most one slice per env is ever waiting
+  // (an env that is in flight is refused by send), so q_tail - q_head <= num_envs < ring_cap and a
+  // cell is never written while it can still be claimed.
+  std::unique_ptr<Cell[]> ring;
+  uint64_t ring_cap = 0;
+  alignas(64) std::atomic<uint64_t> q_head{0};
+  alignas(64) std::atomic<uint64_t> q_tail{0};
+  alignas(64) std::atomic<int> sleepers{0};
+  std::atomic<bool> quitting{false};
+  std::mutex qmu;  // only for going to sleep and waking up
   std::condition_variable qcv;
-  std::deque<Slice> queue;
-  alignas(64) std::atomic<int> q_size{0};  // mirror of queue.size() for the workers' spin phase
   std::vector<std::thread> workers;
   // sync pools: the one batch being filled
   std::mutex smu;
   std::condition_variable scv;
-  uint64_t sync_sent = 0, sync_committed = 0, sync_received = 0;
+  uint64_t sync_sent = 0, sync_committed = 0, sync_received = 0;  // (one batch at a time: sync_sent names the one being filled)
   char* sync_slot = nullptr;
   int sync_n = 0;
-  alignas(64) std::atomic<int> sync_left{0};        // (own cache lines: every record bumps these two)
-  alignas(64) std::atomic<uint32_t> sync_bytes{0};
-  alignas(64) int pad_after_counters = 0;
-  std::vector<uint32_t> sync_offs;
+  alignas(64) std::atomic<int> sync_left{0};  // (its own cache line: every visit counts it down)
+  alignas(64) int pad_after_counter = 0;
   int sync_commit_rc = EP_OK;
   // outcome of callbacks and emits since the last recv
   std::atomic<int> engine_failed{0}, emit_refused{0};
   int64_t recv_timeout_ms = -1;
+  int spin_pauses = 4000;
+  // EP_YGO_POOL_TRACE=1: where a step's time goes, printed at destroy (nanoseconds, summed)
+  bool trace = false;
+  std::atomic<int64_t> t_engine{0}, t_emit{0}, t_commit{0}, t_slices{0};
+  int64_t t_send = 0, t_drain = 0, t_wait = 0, t_collect = 0, n_recv = 0;  // EP_YGO_POOL_SPIN: how long an idle worker looks for work before it sleeps
 };
 
 namespace {
 
-// One env-step on a worker thread: EnvStep (env.h:162-172) with the engine behind the callbacks.
-void run_slice(ep_ygo_pool* p, const Slice& s, std::vector<uint8_t>& scratch) {
-  EnvSlot& e = p->envs[s.env_id - p->env_off];
-  const bool reset = s.force_reset || e.done;  // async_envpool.h:125
-  e.current_step = reset ? 0 : e.current_step + 1;  // env.h:181-189
-  ygo_raw_state st;
-  memset(&st, 0, sizeof(st));
-  int rc = reset ? p->engine.reset(p->engine.ctx, s.env_id, &st) : p->engine.step(p->engine.ctx, s.env_id, s.action, &st);
-  if (rc != 0) {
-    // the row still has to arrive or the batch never completes: an empty record (the no-options
-    // early-out of WriteState), flagged at the next recv
-    p->engine_failed.store(1, std::memory_order_relaxed);
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The env-steps of one visit to the queue, on a worker thread (or on the receiving thread while it
+// waits): EnvStep (env.h:162-172) with the engine behind the callbacks. Sync pools emit each
+// record straight into its row of the pinned slot (row = position in the sent env_id array; the
+// kernel fetches only the used part of a row over PCIe) and count the visit down ONCE (the counter
+// is shared by all threads: per record it was most of a short step's time). Async pools emit into
+// this thread's scratch record and hand it to the arrival ring.
+void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& scratch) {
+  const size_t stride = (size_t)p->stride;
+  if (!p->is_sync && scratch.size() < stride) scratch.resize(stride);
+  for (int i = 0; i < k; ++i) {
+    const Slice& s = sl[i];
+    uint8_t* const rec = p->is_sync ? (uint8_t*)p->sync_slot + stride * (size_t)s.order : scratch.data();
+    EnvSlot& e = p->envs[s.env_id - p->env_off];
+    const bool reset = s.force_reset || e.done;  // async_envpool.h:125
+    e.current_step = reset ? 0 : e.current_step + 1;  // env.h:181-189
+    ygo_raw_state st;
     memset(&st, 0, sizeof(st));
-    st.done = 1;
+    const int64_t c0 = p->trace ? now_ns() : 0;
+    int rc = reset ? p->engine.reset(p->engine.ctx, s.env_id, &st) : p->engine.step(p->engine.ctx, s.env_id, s.action, &st);
+    const int64_t c1 = p->trace ? now_ns() : 0;
+    if (rc != 0) {
+      // the row still has to arrive or the batch never completes: an empty record (the no-options
+      // early-out of WriteState), flagged at the next recv
+      p->engine_failed.store(1, std::memory_order_relaxed);
+      memset(&st, 0, sizeof(st));
+      st.done = 1;
+    }
+    e.done = st.done != 0;
+    st.env_id = s.env_id;              // env.h:208
+    st.elapsed_step = e.current_step;  // env.h:209
+    int erc = ep_ygo_emit_record(&p->cfg, &st, rec);
+    if (erc != EP_OK) {
+      p->emit_refused.store(1, std::memory_order_relaxed);
+      ygo_raw_state empty = st;
+      empty.n_options = 0;
+      (void)ep_ygo_emit_record(&p->cfg, &empty, rec);
+    }
+    e.in_flight.store(0, std::memory_order_release);
+    if (p->trace) { p->t_engine += c1 - c0; p->t_emit += now_ns() - c1; p->t_slices += 1; }
+    if (!p->is_sync && ep_ygo_put_arrival(p->enc, rec) != EP_OK) p->engine_failed.store(1, std::memory_order_relaxed);
   }
-  e.done = st.done != 0;
-  st.env_id = s.env_id;              // env.h:208
-  st.elapsed_step = e.current_step;  // env.h:209
-  if (scratch.size() < (size_t)p->stride) scratch.resize((size_t)p->stride);
-  int erc = ep_ygo_emit_record(&p->cfg, &st, scratch.data());
-  if (erc != EP_OK) {
-    p->emit_refused.store(1, std::memory_order_relaxed);
-    ygo_raw_state empty = st;
-    empty.n_options = 0;
-    (void)ep_ygo_emit_record(&p->cfg, &empty, scratch.data());
-  }
-  e.in_flight.store(0, std::memory_order_release);
-  if (!p->is_sync) {
-    if (ep_ygo_put_arrival(p->enc, scratch.data()) != EP_OK) p->engine_failed.store(1, std::memory_order_relaxed);
-    return;
-  }
-  // sync: bytes back to back in completion order, the offset table puts the record at row `order`
-  const int64_t used = ep_ygo_record_used_bytes(&p->cfg, scratch.data());
-  const uint32_t off = p->sync_bytes.fetch_add((uint32_t)used, std::memory_order_relaxed);
-  memcpy(p->sync_slot + off, scratch.data(), (size_t)used);
-  p->sync_offs[(size_t)s.order] = off;
-  if (p->sync_left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-    const int rc2 = ep_ygo_commit_slot_packed(p->enc, p->sync_n, p->sync_offs.data(), (int64_t)p->sync_bytes.load());
+  if (!p->is_sync) return;
+  const uint64_t batch = p->sync_sent;  // (written before the slices were published)
+  if (p->sync_left.fetch_sub(k, std::memory_order_acq_rel) == k) {
+    const int64_t c3 = p->trace ? now_ns() : 0;
+    const int rc2 = ep_ygo_commit_slot(p->enc, p->sync_n);
+    if (p->trace) p->t_commit += now_ns() - c3;
     std::lock_guard<std::mutex> lk(p->smu);
     p->sync_commit_rc = rc2;
-    p->sync_committed = s.batch;
+    p->sync_committed = batch;
     p->scv.notify_all();
   }
 }
 
-// Takes a fair share of what is queued, at most 8 slices per visit (one lock round trip per slice
-// is what limits a pool whose engine steps are short). `block`: sleep until there is something.
-int take_slices(ep_ygo_pool* p, Slice* mine, bool block) {
-  const size_t nw = p->workers.capacity();  // (reserved to the worker count before the first thread starts)
-  int k = 0;
-  std::unique_lock<std::mutex> lk(p->qmu);
-  if (block) p->qcv.wait(lk, [&] { return !p->queue.empty(); });
-  const size_t share = std::min<size_t>(8, std::max<size_t>(1, p->queue.size() / (2 * nw)));
-  while ((size_t)k < share && !p->queue.empty()) {
-    if (!block && p->queue.front().quit) break;  // quit slices are the workers'
-    mine[k] = p->queue.front();
-    p->queue.pop_front();
-    if (mine[k++].quit) break;  // one quit slice per worker: leave the others theirs
+// Claims a fair share of what is waiting, at most kVisit slices (one visit per slice is what limits
+// a pool whose engine steps are short). The cells are copied BEFORE the claim: once the head has
+// moved past them the sender may reuse them. 0: nothing waiting.
+int take_slices(ep_ygo_pool* p, Slice* mine) {
+  const uint64_t nw = p->workers.capacity();  // (reserved to the worker count before the first thread starts)
+  uint64_t h = p->q_head.load(std::memory_order_acquire);
+  for (;;) {
+    const uint64_t t = p->q_tail.load(std::memory_order_acquire);
+    if (h >= t) return 0;
+    const uint64_t k = std::min<uint64_t>(std::min<uint64_t>((uint64_t)kVisit, t - h), std::max<uint64_t>(1, (t - h) / (2 * nw)));
+    for (uint64_t i = 0; i < k; ++i) mine[i] = p->ring[(h + i) % p->ring_cap].get();
+    if (p->q_head.compare_exchange_weak(h, h + k, std::memory_order_acq_rel, std::memory_order_acquire)) return (int)k;
   }
-  p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
-  return k;
 }
 
 void worker_loop(ep_ygo_pool* p) {  // async_envpool.h:117-128
   std::vector<uint8_t> scratch;
-  Slice mine[8];
+  Slice mine[kVisit];
+  auto waiting = [p] { return p->q_head.load() != p->q_tail.load(); };  // (sequentially consistent: pairs with the sender's publish-then-look)
   for (;;) {
     // like the reference's LightweightSemaphore: look for work for a few tens of microseconds
     // before sleeping in the kernel (a futex wake-up costs more than a short engine step)
-    for (int spin = 0; spin < 4000 && p->q_size.load(std::memory_order_relaxed) == 0; ++spin) __builtin_ia32_pause();
-    const int k = take_slices(p, mine, true);
-    for (int i = 0; i < k; ++i) {
-      if (mine[i].quit) return;
-      run_slice(p, mine[i], scratch);
+    for (int spin = 0; spin < p->spin_pauses && !waiting() && !p->quitting.load(std::memory_order_relaxed); ++spin)
+      __builtin_ia32_pause();
+    const int k = take_slices(p, mine);
+    if (k > 0) {
+      run_slices(p, mine, k, scratch);
+      continue;
     }
+    // what was sent before destroy is still stepped (async_envpool.h:144-154 queues its empty
+    // slices BEHIND the pending ones)
+    if (p->quitting.load(std::memory_order_acquire)) return;
+    std::unique_lock<std::mutex> lk(p->qmu);
+    p->sleepers.fetch_add(1);  // (sequentially consistent, like the sender's look at it after publishing)
+    p->qcv.wait(lk, [&] { return waiting() || p->quitting.load(std::memory_order_acquire); });
+    p->sleepers.fetch_sub(1);
   }
 }
 
@@ -206,6 +250,7 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
   if (!p || (n > 0 && !env_id) || (n > 0 && !force_reset && !action)) return fail(EP_ERR_INVALID, "null argument");
   if (n < 0 || n > p->N) return fail(EP_ERR_TOO_LARGE, "n = %d outside [0, num_envs = %d]", n, p->N);
   if (n == 0) return EP_OK;
+  const int64_t s0 = p->trace ? now_ns() : 0;
   // one sender at a time (action_buffer_queue.h:60-68)
   std::unique_lock<std::mutex> sl(p->smu);
   if (++p->stamp_val == 0) {
@@ -222,7 +267,6 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     if (p->envs[e].in_flight.load(std::memory_order_acquire))
       return fail(EP_ERR_INVALID, "env %d is still stepping: receive its state before sending it again", env_id[i]);
   }
-  uint64_t batch = 0;
   if (p->is_sync) {
     if (p->sync_sent != p->sync_received)
       return fail(EP_ERR_INVALID, "sync pool: receive the batch of the previous send / reset first");
@@ -232,18 +276,19 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     p->sync_slot = (char*)slot;
     p->sync_n = n;
     p->sync_left.store(n, std::memory_order_relaxed);
-    p->sync_bytes.store(0, std::memory_order_relaxed);
-    p->sync_offs.assign((size_t)n, 0u);
-    batch = ++p->sync_sent;
+    ++p->sync_sent;
   }
-  for (int i = 0; i < n; ++i) p->envs[env_id[i] - p->env_off].in_flight.store(1, std::memory_order_relaxed);
-  {
-    std::lock_guard<std::mutex> lk(p->qmu);
-    for (int i = 0; i < n; ++i)
-      p->queue.push_back(Slice{env_id[i], p->is_sync ? i : -1, force_reset ? 0 : action[i], force_reset, false, batch});
-    p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
+  const uint64_t t = p->q_tail.load(std::memory_order_relaxed);  // senders are serialised by smu
+  for (int i = 0; i < n; ++i) {
+    p->envs[env_id[i] - p->env_off].in_flight.store(1, std::memory_order_relaxed);
+    p->ring[(t + (uint64_t)i) % p->ring_cap].put(Slice{env_id[i], p->is_sync ? i : -1, force_reset ? 0 : action[i], force_reset});
   }
-  p->qcv.notify_all();
+  p->q_tail.store(t + (uint64_t)n);  // publishes the cells, the in-flight flags and the sync batch's set-up
+  if (p->sleepers.load() > 0) {
+    { std::lock_guard<std::mutex> lk(p->qmu); }  // a worker between its last look and its sleep is past it now
+    p->qcv.notify_all();
+  }
+  if (p->trace) p->t_send += now_ns() - s0;
   return EP_OK;
 }
 
@@ -276,8 +321,15 @@ int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, in
   }
   p->envs.reset(new EnvSlot[(size_t)num_envs]);
   p->stamp.assign((size_t)num_envs, 0u);
+  p->ring_cap = 2 * (uint64_t)num_envs + 16;  // action_buffer_queue.h: 2 * num_envs
+  p->ring.reset(new Cell[p->ring_cap]);
+  if (const char* e = getenv("EP_YGO_POOL_TRACE")) p->trace = atoi(e) != 0;
+  if (const char* e = getenv("EP_YGO_POOL_SPIN")) p->spin_pauses = std::max(0, atoi(e));
   const unsigned hw = usable_cpus();
-  if (num_threads <= 0) num_threads = (int32_t)std::min<unsigned>((unsigned)p->B, hw);  // async_envpool.h:113-115
+  // async_envpool.h:113-115: min(batch, hardware_concurrency). A sync pool's receiving thread steps envs
+  // itself while it waits (ep_ygo_pool_recv), so it counts as one of them: with a worker per CPU
+  // besides, the sender would share a CPU with a spinning worker.
+  if (num_threads <= 0) num_threads = (int32_t)std::min<unsigned>((unsigned)p->B, p->is_sync ? std::max(1u, hw - 1) : hw);
   p->workers.reserve((size_t)num_threads);
   for (int t = 0; t < num_threads; ++t) {
     p->workers.emplace_back(worker_loop, p.get());
@@ -294,14 +346,20 @@ int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, in
 
 int ep_ygo_pool_destroy(ep_ygo_pool* p) {
   if (!p) return EP_OK;
-  {  // async_envpool.h:144-154: one empty slice per worker
+  {  // async_envpool.h:144-154 (there: one empty slice per worker behind the pending ones)
     std::lock_guard<std::mutex> lk(p->qmu);
-    for (size_t i = 0; i < p->workers.size(); ++i) p->queue.push_back(Slice{0, -1, 0, false, true, 0});
-    p->q_size.store((int)p->queue.size(), std::memory_order_relaxed);
+    p->quitting.store(true);
   }
   p->qcv.notify_all();
   if (!p->is_sync) (void)ep_ygo_async_end(p->enc);  // workers asleep on a full ring (nobody received) must come back
   for (auto& w : p->workers) w.join();
+  if (p->trace && p->n_recv > 0) {
+    const double k = 1e-3 / (double)p->n_recv, ns = (double)std::max<int64_t>(1, p->t_slices.load());
+    fprintf(stderr, "[ep_ygo_pool trace] %lld sync recvs, %zu workers; per step: send %.1f us, recv drain (helping) %.1f, wait for commit %.1f, "
+            "collect %.1f; per env-step: engine callback %.2f us, emit %.2f; commit call %.1f us per step\n",
+            (long long)p->n_recv, p->workers.size(), p->t_send * k, p->t_drain * k, p->t_wait * k, p->t_collect * k,
+            p->t_engine.load() / ns * 1e-3, p->t_emit.load() / ns * 1e-3, p->t_commit.load() * k);
+  }
   int rc = ep_ygo_encoder_destroy(p->enc);
   delete p;
   return rc;
@@ -330,13 +388,14 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
       std::lock_guard<std::mutex> lk(p->smu);
       if (p->sync_sent == p->sync_received) return fail(EP_ERR_WOULD_BLOCK, "nothing was sent");
     }
+    const int64_t r0 = p->trace ? now_ns() : 0;
     if (p->recv_timeout_ms != 0) {
       // the caller would only sleep until the batch is complete: let it step envs meanwhile
       static thread_local std::vector<uint8_t> scratch;
-      Slice mine[8];
-      for (int k; (k = take_slices(p, mine, false)) > 0;)
-        for (int i = 0; i < k; ++i) run_slice(p, mine[i], scratch);
+      Slice mine[kVisit];
+      for (int k; (k = take_slices(p, mine)) > 0;) run_slices(p, mine, k, scratch);
     }
+    const int64_t r1 = p->trace ? now_ns() : 0;
     {
       std::unique_lock<std::mutex> lk(p->smu);
       const uint64_t want = p->sync_sent;
@@ -352,9 +411,11 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
         return fail(p->sync_commit_rc, "the encoder refused the batch");
       }
     }
+    const int64_t r2 = p->trace ? now_ns() : 0;
     rc = ep_ygo_collect(p->enc, mem_out, out);
     std::lock_guard<std::mutex> lk(p->smu);
     p->sync_received = p->sync_sent;
+    if (p->trace) { p->t_drain += r1 - r0; p->t_wait += r2 - r1; p->t_collect += now_ns() - r2; ++p->n_recv; }
   } else {
     rc = ep_ygo_recv(p->enc, mem_out, out);
   }
@@ -370,8 +431,7 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
 int ep_ygo_pool_set_env_id_offset(ep_ygo_pool* p, int32_t env_id_offset) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->smu);
-  std::lock_guard<std::mutex> lq(p->qmu);
-  if (!p->queue.empty() || p->sync_sent != 0) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
+  if (p->q_tail.load() != 0 || p->sync_sent != 0) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
   for (int i = 0; i < p->N; ++i)
     if (p->envs[i].current_step != -1) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
   p->env_off = env_id_offset;

@@ -216,7 +216,9 @@ int64_t ep_ygo_record_used_bytes(const ep_ygo_config* cfg, const void* record);
 /* The packed form for ONE producer (submit / collect mode): the caller fills the slot it got from
  * ep_ygo_acquire_slot with n records back to back (record i at byte offsets[i], 16-byte aligned,
  * used_bytes in all) and commits; or lets ep_ygo_emit_records_packed (below, with the raw-state
- * type) emit n states that way. Collected with ep_ygo_collect like any other batch. */
+ * type) emit n states that way. Collected with ep_ygo_collect like any other batch. With nothing
+ * else in flight the kernel reads the slot in place (one launch); a batch committed behind another
+ * one is moved by the copy engine under that one's kernel. */
 int ep_ygo_commit_slot_packed(ep_ygo_encoder* enc, int32_t n, const uint32_t* offsets, int64_t used_bytes);
 /* Counters of the arrival-ordered ring since ep_ygo_async_begin: the time producer threads spent
  * waiting for a free slot (the only place where the GPU side can hold the duel threads up), the
@@ -302,7 +304,8 @@ int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, 
  *               ep_ygo_collect. batch_size < num_envs: rows in arrival order; batch_size ==
  *               num_envs (sync): row i is position i of the sent env_id array (:69), and a sync pool
  *               takes one send / reset per recv.
- * num_threads <= 0: min(batch_size, hardware threads) (:113-115); thread_affinity_offset < 0: none. */
+ * num_threads <= 0: min(batch_size, CPUs this process may use) (:113-115), one fewer for a sync pool,
+ * whose receiving thread steps envs too; thread_affinity_offset < 0: none. */
 typedef struct {
   void* ctx;
   int (*reset)(void* ctx, int32_t env_id, ygo_raw_state* state);

@@ -398,7 +398,8 @@ def test_featurize_returns_its_own_batch():
 
 def test_single_producer_packed_slot():
   """Submit / collect mode with the slot filled in the packed form (records back to back + offset
-  table, one copy-engine transfer of the bytes in use): ep_ygo_emit_records_packed, and
+  table; read in place by the kernel when nothing else is in flight, else one copy-engine transfer
+  of the bytes in use): ep_ygo_emit_records_packed, and
   ep_ygo_commit_slot_packed with a caller-packed slot, against the oracle."""
   import ctypes as C
 
@@ -431,6 +432,18 @@ def test_single_producer_packed_slot():
     pos += lens[i]
   capi._check(L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos))
   _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, "commit_slot_packed")
+  # with nothing else in flight the kernel reads the packed slot in place; a batch committed behind
+  # another one goes through the copy engine: both, back to back
+  for _ in range(2):
+    capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
+    pos = 0
+    for i in reversed(range(n)):
+      C.memmove(slot.value + pos, recs[i].ctypes.data, lens[i])
+      offs[i] = pos
+      pos += lens[i]
+    capi._check(L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos))
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, "commit_slot_packed, in place")
+  _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, "commit_slot_packed, copy engine")
   offs[3] += 4
   capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
   assert L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos) == capi.EP_ERR_INVALID

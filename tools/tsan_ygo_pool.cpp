@@ -132,6 +132,17 @@ int ep_ygo_commit_slot_packed(ep_ygo_encoder* e, int32_t n, const uint32_t* offs
   e->has_committed = true;
   return EP_OK;
 }
+int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {  // fixed stride: row i at i * kStride
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->committed.clear();
+  for (int i = 0; i < n; ++i) {
+    MockRec r;
+    memcpy(&r, e->slot.data() + (size_t)i * kStride, sizeof(r));
+    e->committed.push_back(r);
+  }
+  e->has_committed = true;
+  return EP_OK;
+}
 int ep_ygo_collect(ep_ygo_encoder* e, int32_t, ep_batch* out) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->has_committed) return EP_ERR_WOULD_BLOCK;
