@@ -307,7 +307,7 @@ def run_config5_pool(device=0, threads_list=(4, 16), n_envs=1024, batch=512, bat
   return out
 
 
-def run_config3_pool(device=0, threads_list=(4, 16), n_envs=1024, steps=150, engine_us=0.0):
+def run_config3_pool(device=0, threads_list=(4, 0), n_envs=1024, steps=150, engine_us=0.0):
   """BASELINE config 3 as a POOL (ep_ygo_pool, sync: batch_size = num_envs = 1024): one step =
   send 1024 actions, the workers run the (stand-in, here free) engine and emit the records, the last
   one commits the packed slot, recv waits for the encode. PCIe-inclusive, emission included."""
@@ -340,7 +340,8 @@ def run_config3_pool(device=0, threads_list=(4, 16), n_envs=1024, steps=150, eng
       if i >= 20:
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    out["by_threads"][str(nt)] = {"us_per_step_median": ts[len(ts) // 2] * 1e6, "env_steps_per_s": n_envs / ts[len(ts) // 2]}
+    # (0 asks for the pool's default: one worker per usable CPU but one, the receiving thread steps envs too)
+    out["by_threads"][str(pool.num_threads)] = {"us_per_step_median": ts[len(ts) // 2] * 1e6, "env_steps_per_s": n_envs / ts[len(ts) // 2]}
     pool.close()
     eng.close()
   return out
