@@ -5,11 +5,11 @@ namespace epk_mp {
 
 // Fills and launches mp_step_fused for `cnt` items. `sc` / `ticket_base` / epochs: see
 // dummy_mp_kernels.hpp. Shared by the pool path and ep_dummy_send_noalloc.
-int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count) {
+int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count, bool force_ticket) {
   a.n = cnt;
   a.num_tiles = (cnt + epk::kMpTile - 1) / epk::kMpTile;
   // a CU holds 8 workgroups of 256 threads; half of that is the bound for "all tiles at once"
-  a.static_tiles = (a.num_tiles <= 4 * cu_count && !getenv("EP_MP_FORCE_TICKET")) ? 1 : 0;  // (the variable: tests of the ticket path)
+  a.static_tiles = (a.num_tiles <= 4 * cu_count && !force_ticket) ? 1 : 0;
   hipLaunchKernelGGL(epk::mp_step_fused, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
@@ -83,7 +83,7 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     a.first_segment = sh.alloc_count == 0 ? 1 : 0;
     {
       TimedScope ts(p);
-      if (int rc = launch_fused(p->stream, a, cnt, p->cu_count)) return rc;
+      if (int rc = launch_fused(p->stream, a, cnt, p->cu_count, p->mp_force_ticket)) return rc;
     }
     if (!a.static_tiles) p->mp_ticket_total += (uint32_t)a.num_tiles;
     sh.alloc_count += cnt;

@@ -138,6 +138,7 @@ struct ep_pool {
   bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
   int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
   bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
+  bool mp_force_ticket = false;  // EP_MP_FORCE_TICKET=1: multi-player tile ids from the ticket counter even when the launch fits (tests)
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -706,6 +707,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (p->Q < 2) return fail(EP_ERR_INVALID, "ring_depth must be >= 2");
   p->device = cfg->device_id;
   if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
+  if (const char* ft = getenv("EP_MP_FORCE_TICKET")) p->mp_force_ticket = ft[0] != '0';
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
@@ -1601,7 +1603,7 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   a.force_reset = force_reset ? 1 : 0;
   a.P = P;
   a.first_segment = 1;
-  return epk_mp::launch_fused(st, a, n, cus);
+  return epk_mp::launch_fused(st, a, n, cus, false);
 }
 
 int32_t ep_pool_num_envs(ep_pool* p) { return p ? p->N : 0; }

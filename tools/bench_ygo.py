@@ -321,6 +321,8 @@ def run_config3_pool(device=0, threads_list=(4, 0), n_envs=1024, steps=150, engi
   out = {"envs": n_envs, "engine_us_per_env_step": engine_us, "by_threads": {}}
   ok = (0, capi.EP_ERR_ACTION_CHECK)
   for nt in threads_list:
+    if nt == 0:  # the pool's default for one GPU's share of a node (16 CPUs), also where the job sees the whole machine
+      nt = 0 if len(os.sched_getaffinity(0)) <= 16 else 15
     cfg = capi_ygo.default_config(max_batch=n_envs, ring_depth=0, device_id=device)
     eng = ygo_synth.SynthEngine(cfg, table, n_envs, seed=5, engine_us=engine_us)
     eng.set_replay()
