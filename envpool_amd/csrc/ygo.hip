@@ -528,12 +528,7 @@ int ep_ygo_emit_records_packed(ep_ygo_encoder* e, const ygo_raw_state* in, int32
     // (the emitter clears a whole stride: it writes into the scratch record, the used prefix moves on)
     int erc = ep_ygo_emit_record(&e->cfg, in + i, scratch.data());
     if (status) status[i] = erc;
-    if (erc) {
-      if (!first) first = erc;
-      ygo_raw_state empty = in[i];
-      empty.n_options = 0;
-      if ((erc = ep_ygo_emit_record(&e->cfg, &empty, scratch.data()))) return erc;
-    }
+    if (erc && !first) first = erc;  // (the record is then the state's empty observation)
     const int64_t len = ep_ygo_record_used_bytes(&e->cfg, scratch.data());
     memcpy((char*)slot + used, scratch.data(), (size_t)len);
     offs[(size_t)i] = (uint32_t)used;
@@ -1157,10 +1152,38 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
 
 extern "C" {
 
+}  // extern "C"
+
+static int emit_record_impl(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
+
+extern "C" {
+
+// A state that cannot be parsed must not leave a half-written record (counts without their cards)
+// where a caller may encode it: the record becomes the state's empty observation (no options: the
+// early-out of WriteState), and the parse error is what the call returns.
 int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out) {
   int rc = check_config(cfg);
   if (rc) return rc;
   if (!in || !record_out) return fail(EP_ERR_INVALID, "null argument");
+  rc = emit_record_impl(cfg, in, record_out);
+  if (rc == EP_OK) return rc;
+  const std::string why = epc::g_last_error;
+  ygo_raw_state empty = *in;
+  empty.n_options = 0;
+  if (emit_record_impl(cfg, &empty, record_out) != EP_OK) {  // (to_play or ha_p out of range)
+    memset(record_out, 0, (size_t)make_layout(*cfg).stride);
+    ygo_header* h = (ygo_header*)record_out;
+    h->env_id = in->env_id;
+    h->elapsed_step = in->elapsed_step;
+    h->done = in->done ? 1 : 0;
+  }
+  return fail(rc, "%s", why.c_str());
+}
+
+}  // extern "C"
+
+static int emit_record_impl(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out) {
+  int rc;
   const Layout lay = make_layout(*cfg);
   uint8_t* rec = (uint8_t*)record_out;
   memset(rec, 0, (size_t)lay.stride);
@@ -1242,6 +1265,8 @@ int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* 
   }
   return EP_OK;
 }
+
+extern "C" {
 
 int ep_ygo_emit_records(const ep_ygo_config* cfg, const ygo_raw_state* in, int32_t n, void* records_out,
                         int32_t* status) {

@@ -149,13 +149,8 @@ void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& sc
     e.done = st.done != 0;
     st.env_id = s.env_id;              // env.h:208
     st.elapsed_step = e.current_step;  // env.h:209
-    int erc = ep_ygo_emit_record(&p->cfg, &st, rec);
-    if (erc != EP_OK) {
-      p->emit_refused.store(1, std::memory_order_relaxed);
-      ygo_raw_state empty = st;
-      empty.n_options = 0;
-      (void)ep_ygo_emit_record(&p->cfg, &empty, rec);
-    }
+    // (a state the emitter cannot parse comes back as its empty observation: the row still arrives)
+    if (ep_ygo_emit_record(&p->cfg, &st, rec) != EP_OK) p->emit_refused.store(1, std::memory_order_relaxed);
     e.in_flight.store(0, std::memory_order_release);
     if (p->trace) { p->t_engine += c1 - c0; p->t_emit += now_ns() - c1; p->t_slices += 1; }
     if (!p->is_sync && ep_ygo_put_arrival(p->enc, rec) != EP_OK) p->engine_failed.store(1, std::memory_order_relaxed);

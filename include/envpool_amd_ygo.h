@@ -259,9 +259,9 @@ typedef struct {
 
 /* Parses the raw query buffers (get_cards_in_location, :2060-2137) and the option strings
  * (grammar of _set_obs_action, :1674-1765) into one record. Host only, no GPU. Returns
- * EP_ERR_INVALID on input the reference would throw on while parsing; record_out is then half
- * written (counts without their cards) and must not be encoded: emit the state again with
- * n_options = 0 (an empty observation) in its place, as ep_ygo_emit_records_packed and the pool do. */
+ * EP_ERR_INVALID on input the reference would throw on while parsing; record_out then holds the
+ * state's EMPTY observation (what emitting it with n_options = 0 gives: the early-out of WriteState),
+ * so a batch that contains it can still be encoded and keeps its row. */
 int ep_ygo_emit_record(const ep_ygo_config* cfg, const ygo_raw_state* in, void* record_out);
 
 /* Packed arrival-ordered ring, one call per finished env-step (see ep_ygo_set_packed above). */

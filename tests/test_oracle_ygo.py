@@ -199,3 +199,26 @@ def test_synthetic_states_are_well_formed():
   assert (est == 0).all()
   nopt = outs[12]
   assert nopt.min() >= 1 and nopt.max() == 16 and (outs[8].reshape(3000, -1).any(axis=1)).mean() > 0.95
+
+
+def test_refused_state_leaves_an_empty_record():
+  """A state the emitter cannot parse (here: more listed cards than 2 * max_cards, where the
+  reference overruns obs:cards_) must not leave counts without their cards behind: the record is
+  the state's empty observation, byte for byte what emitting it with n_options = 0 gives."""
+  import ctypes as C
+  from envpool_amd import capi
+  from tools import ygo_synth
+  small = capi_ygo.default_config(max_batch=64, max_cards=4)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(small, table, 64, seed=3)
+  recs, est = capi_ygo.emit_records(small, sb.raw, 64)
+  bad = np.flatnonzero(est != 0)
+  assert bad.size > 32 and (est[bad] == capi.EP_ERR_INVALID).all()
+  stride = recs.shape[1]
+  for i in bad[:8]:
+    empty = capi_ygo.RawState()
+    C.memmove(C.byref(empty), C.byref(sb.raw[int(i)]), C.sizeof(capi_ygo.RawState))
+    empty.n_options = 0
+    want, e2 = capi_ygo.emit_records(small, (capi_ygo.RawState * 1)(empty), 1)
+    assert e2[0] == 0 and recs[i].tobytes() == want[0].tobytes()
+    assert capi_ygo.lib().ep_ygo_record_used_bytes(C.byref(small), recs[i].ctypes.data) < stride

@@ -44,10 +44,7 @@ def main(total=int(os.environ.get("SOAK_RECORDS", "600000"))):
     sb = ygo_synth.SynthBatch(cfg, table, n, seed=seed)
     want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
     recs, est = capi_ygo.emit_records(cfg, sb.raw, n)
-    # a state the emitter refuses leaves a half-written record behind (counts without cards): what a
-    # caller sends in its place is an empty record (ep_ygo_emit_records_packed and the pool do that
-    # themselves), so the batch's flag below speaks of the emitted records only
-    recs[est != 0] = 0
+    # (a state the emitter refuses comes back as its empty observation: it raises no flag of its own)
     ok = np.nonzero((status == 0) & (est == 0))[0]
     got = enc.featurize(recs, allow=(capi.EP_ERR_ACTION_CHECK,))
     flagged = enc.last_status == capi.EP_ERR_ACTION_CHECK
