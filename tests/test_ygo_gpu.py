@@ -448,3 +448,12 @@ def test_single_producer_packed_slot():
   capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
   assert L.ep_ygo_commit_slot_packed(enc.handle, n, offs.ctypes.data, pos) == capi.EP_ERR_INVALID
   enc.close()
+
+
+def test_corrupted_records_do_not_disturb_their_neighbours(monkeypatch):
+  """Records are caller-supplied bytes: valid records with random bytes overwritten, counts at their
+  maximum, and pure noise, host and device-resident (tools/ygo_record_fuzz.py, a few rounds of it).
+  The batch comes back whole and the untouched records equal their clean encoding."""
+  from tools import ygo_record_fuzz
+  monkeypatch.setenv("FUZZ_SEED", "3")
+  ygo_record_fuzz.main(rounds=4)
