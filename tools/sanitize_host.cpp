@@ -6,7 +6,7 @@
 // Inputs: synthetic duel states in the reference's data forms (tools/ygo_synth.c), emitted into
 // heap blocks of EXACTLY the record stride (so any write past a record is caught), then the same
 // states with their option / revealed strings garbled, truncated or replaced by strings of the
-// wrong message type: the emitter must return EP_OK or EP_ERR_INVALID and touch nothing it does
+// wrong message type, and with their query buffers garbled and truncated: the emitter must return EP_OK or EP_ERR_INVALID and touch nothing it does
 // not own. Exit status 0 = no sanitizer report (the sanitizers abort the process otherwise).
 #include <stdint.h>
 #include <stdio.h>
@@ -68,8 +68,36 @@ int main(int argc, char** argv) {
         }
         if (variant == 3) raw->ha_p[rnd() % 2] = (int32_t)(rnd() % 16);
       }
+      // variant 3 also garbles / truncates the query_field_card buffers, each moved into a heap block
+      // of exactly its length so that a read past the end is caught
+      std::vector<uint8_t*> owned;
+      const uint8_t* keep_buf[2][7];
+      int32_t keep_len[2][7];
+      memcpy(keep_buf, raw->field_buf, sizeof(keep_buf));
+      memcpy(keep_len, raw->field_len, sizeof(keep_len));
+      if (variant == 3) {
+        for (int pl = 0; pl < 2; ++pl)
+          for (int li = 0; li < 7; ++li) {
+            int32_t len = raw->field_len[pl][li];
+            if (!raw->field_buf[pl][li] || len <= 0) continue;
+            if (rnd() % 3 == 0) len = (int32_t)(rnd() % (uint64_t)(len + 1));  // truncated anywhere
+            uint8_t* blk = (uint8_t*)malloc((size_t)(len ? len : 1));
+            memcpy(blk, raw->field_buf[pl][li], (size_t)len);
+            const int hits = (int)(rnd() % 4);
+            for (int h = 0; h < hits && len; ++h) {
+              const size_t at = (size_t)(rnd() % (uint64_t)len);
+              blk[at] = rnd() % 2 ? 0xff : (uint8_t)rnd();  // (0xff in a count word: "4 billion overlay units")
+            }
+            owned.push_back(blk);
+            raw->field_buf[pl][li] = blk;
+            raw->field_len[pl][li] = len;
+          }
+      }
       void* rec = malloc((size_t)stride);
       const int rc = ep_ygo_emit_record(&cfg, raw, rec);
+      memcpy(raw->field_buf, keep_buf, sizeof(keep_buf));
+      memcpy(raw->field_len, keep_len, sizeof(keep_len));
+      for (uint8_t* b : owned) free(b);
       if (rc == EP_OK) {
         ++ok;
         const int64_t used = ep_ygo_record_used_bytes(&cfg, rec);
