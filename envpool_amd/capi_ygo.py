@@ -53,7 +53,7 @@ SYMBOLS = [
   "ep_ygo_emit_record", "ep_ygo_emit_records", "ep_ygo_history_push", "ep_ygo_set_zero_copy", "ep_ygo_submit_device",
   "ep_ygo_async_begin", "ep_ygo_async_end", "ep_ygo_alloc_record", "ep_ygo_record_done", "ep_ygo_recv", "ep_ygo_set_recv_timeout",
   "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
-  "ep_ygo_commit_slot_packed", "ep_ygo_emit_records_packed",
+  "ep_ygo_commit_slot_packed", "ep_ygo_commit_slot_rows", "ep_ygo_emit_records_packed",
   "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
   "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads", "ep_ygo_pool_set_env_id_offset",
 ]
@@ -109,6 +109,7 @@ def lib():
     L.ep_ygo_record_used_bytes.argtypes = [C.POINTER(YgoConfig), vp]
     L.ep_ygo_record_used_bytes.restype = i64
     L.ep_ygo_commit_slot_packed.argtypes = [vp, i32, vp, i64]
+    L.ep_ygo_commit_slot_rows.argtypes = [vp, i32, i32, i32, vp]
     L.ep_ygo_emit_records_packed.argtypes = [vp, C.POINTER(RawState), i32, vp]
     L.ep_ygo_ring_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.ep_ygo_pool_create.argtypes = [C.POINTER(YgoConfig), C.POINTER(Engine), i32, i32, i32, i32, C.POINTER(CardData), i32,

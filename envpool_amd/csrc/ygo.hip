@@ -62,6 +62,7 @@ struct Slot {
   char* d_out = nullptr;   // all output keys of one batch
   hipEvent_t copied = nullptr, done = nullptr;
   int n = 0;
+  int rows_launched = 0;  // ep_ygo_commit_slot_rows: rows of the batch being filled that are on their way
   bool busy = false;
 };
 
@@ -135,14 +136,16 @@ void out_ptrs(ep_ygo_encoder* e, char* base, ygk::Outs* o) {
   o->action_mask = (uint8_t*)(base + e->key_off[17]);
 }
 
+// Rows [row0, row0 + n) of the batch in `slot`; `d_records` is the batch's first record.
 int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot, bool lean_fetch = false, hipStream_t st = nullptr,
-           const uint32_t* d_offsets = nullptr) {
+           const uint32_t* d_offsets = nullptr, int row0 = 0) {
   if (!st) st = e->stream;
   ygk::Args a;
   a.records = (const uint8_t*)d_records;
   a.offsets = d_offsets;
   a.stride = e->lay.stride;
-  a.n = n;
+  a.n = row0 + n;
+  a.row0 = row0;
   a.table = e->d_table;
   a.table_aux = e->d_table_aux;
   a.table_mask = e->table_mask;
@@ -454,6 +457,8 @@ static int commit_slot_impl(ep_ygo_encoder* e, int32_t n, const uint32_t* offset
   HIP_TRY(hipSetDevice(e->device));
   const int si = (int)(e->submit_idx % e->slots.size());
   Slot& s = e->slots[si];
+  if (s.rows_launched != 0)
+    return fail(EP_ERR_INVALID, "%d rows of this batch went out through ep_ygo_commit_slot_rows: finish it there", s.rows_launched);
   s.n = n;
   hipStream_t st = e->stream;
   if (n > 0 && offsets) {
@@ -506,6 +511,49 @@ static int commit_slot_impl(ep_ygo_encoder* e, int32_t n, const uint32_t* offset
 }
 
 extern "C" {
+
+int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int32_t n_total, int32_t* completed) {
+  if (!e || !completed) return fail(EP_ERR_INVALID, "null argument");
+  *completed = 0;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->async_B) return fail(EP_ERR_INVALID, "the encoder is in arrival-ordered mode (ep_ygo_async_begin)");
+  if (n_total < 1 || n_total > e->cfg.max_batch || row0 < 0 || n_rows < 1 || row0 > n_total - n_rows)
+    return fail(EP_ERR_INVALID, "rows [%d, %d + %d) of a batch of %d (max_batch = %d)", row0, row0, n_rows, n_total, e->cfg.max_batch);
+  if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
+  if (e->submit_idx - e->collect_idx >= e->slots.size())
+    return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
+  HIP_TRY(hipSetDevice(e->device));
+  const int si = (int)(e->submit_idx % e->slots.size());
+  Slot& s = e->slots[si];
+  if (s.rows_launched + n_rows > n_total)
+    return fail(EP_ERR_INVALID, "%d rows of this batch of %d are committed already", s.rows_launched, n_total);
+  // every part of one batch goes to ONE stream (consecutive batches alternate, as in ep_ygo_commit_slot):
+  // the event behind the last part covers them all
+  hipStream_t st = (e->submit_idx & 1) ? e->copy_stream : e->stream;
+  int rc;
+  if (e->zero_copy) {
+    void* dev_view = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev_view, s.h_rec, 0));
+    rc = launch(e, (const char*)dev_view, n_rows, si, /*lean_fetch=*/true, st, nullptr, row0);
+  } else {
+    st = e->stream;
+    const size_t off = (size_t)row0 * (size_t)e->lay.stride;
+    HIP_TRY(hipMemcpyAsync(s.d_rec + off, s.h_rec + off, (size_t)n_rows * e->lay.stride, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+    rc = launch(e, s.d_rec, n_rows, si, false, st, nullptr, row0);
+  }
+  if (rc) return rc;
+  s.rows_launched += n_rows;
+  if (s.rows_launched < n_total) return EP_OK;
+  s.rows_launched = 0;
+  s.n = n_total;
+  HIP_TRY(hipEventRecord(s.done, st));
+  s.busy = true;
+  e->submit_idx++;
+  *completed = 1;
+  return EP_OK;
+}
 
 // Emits `n` states straight into the next pinned slot in the packed form and commits it: the
 // single-producer counterpart of ep_ygo_emit_arrival (a sync pool whose host thread has all n

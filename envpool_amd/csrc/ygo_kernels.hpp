@@ -108,7 +108,8 @@ struct Args {
   const uint8_t* records;
   const uint32_t* offsets;  // packed records: byte offset of record i from `records` (16-byte aligned); null: i * stride
   int64_t stride;
-  int32_t n;
+  int32_t n;     // rows [row0, n) of the batch are this launch's
+  int32_t row0;
   const HashEntry* table;
   const HashAux* table_aux;
   uint32_t table_mask;  // capacity - 1
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
 #endif
   const int R = 2 * a.max_cards, nf = a.nf;
   const int hist_bytes = a.n_hist * nf;
-  const int64_t e = (int64_t)blockIdx.x * kGroup + wave;
+  const int64_t e = (int64_t)a.row0 + (int64_t)blockIdx.x * kGroup + wave;
   if (e >= a.n) return;  // wave-uniform; no workgroup barrier anywhere in this kernel
 
   const int arena = wave * cv.wave_stride;

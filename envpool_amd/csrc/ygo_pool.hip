@@ -100,8 +100,15 @@ struct ep_ygo_pool {
   uint64_t sync_sent = 0, sync_committed = 0, sync_received = 0;  // (one batch at a time: sync_sent names the one being filled)
   char* sync_slot = nullptr;
   int sync_n = 0;
-  alignas(64) std::atomic<int> sync_left{0};  // (its own cache line: every visit counts it down)
-  alignas(64) int pad_after_counter = 0;
+  // The batch goes to the encoder in up to kMaxParts parts of consecutive rows, each as soon as its
+  // rows are emitted: slices are claimed in sent order, so the early rows are done while the late
+  // ones are still being stepped, and their encode (launch, PCIe reads, kernel) runs under that.
+  struct alignas(64) PartLeft { std::atomic<int> v{0}; };  // (own cache lines: every visit counts one down)
+  static constexpr int kMaxParts = 8;
+  PartLeft sync_left[kMaxParts];
+  int sync_parts = 1, sync_part_rows = 0;
+  int max_parts = 4;  // EP_YGO_POOL_PARTS
+  alignas(64) int pad_after_counters = 0;
   int sync_commit_rc = EP_OK;
   // outcome of callbacks and emits since the last recv
   std::atomic<int> engine_failed{0}, emit_refused{0};
@@ -156,15 +163,28 @@ void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& sc
     if (!p->is_sync && ep_ygo_put_arrival(p->enc, rec) != EP_OK) p->engine_failed.store(1, std::memory_order_relaxed);
   }
   if (!p->is_sync) return;
+  // The batch's set-up is read BEFORE this visit's first count-down: once the last one is done the
+  // batch may complete, be received, and the next send rewrite it.
   const uint64_t batch = p->sync_sent;  // (written before the slices were published)
-  if (p->sync_left.fetch_sub(k, std::memory_order_acq_rel) == k) {
+  const int parts = p->sync_parts, part_rows = p->sync_part_rows, n_total = p->sync_n;
+  int per_part[ep_ygo_pool::kMaxParts] = {0};
+  for (int i = 0; i < k; ++i) per_part[sl[i].order / part_rows] += 1;
+  for (int part = 0; part < parts; ++part) {
+    const int mine = per_part[part];
+    if (mine == 0 || p->sync_left[part].v.fetch_sub(mine, std::memory_order_acq_rel) != mine) continue;
+    // this visit finished the part: its rows go to the encoder now
+    const int row0 = part * part_rows, rows = std::min(part_rows, n_total - row0);
     const int64_t c3 = p->trace ? now_ns() : 0;
-    const int rc2 = ep_ygo_commit_slot(p->enc, p->sync_n);
+    int32_t completed = 0;
+    const int rc2 = ep_ygo_commit_slot_rows(p->enc, row0, rows, n_total, &completed);
     if (p->trace) p->t_commit += now_ns() - c3;
-    std::lock_guard<std::mutex> lk(p->smu);
-    p->sync_commit_rc = rc2;
-    p->sync_committed = batch;
-    p->scv.notify_all();
+    if (rc2 == EP_OK && !completed) continue;
+    std::lock_guard<std::mutex> lk(p->smu);  // the batch is on its way, or never will be
+    if (p->sync_committed != batch) {
+      p->sync_commit_rc = rc2;
+      p->sync_committed = batch;
+      p->scv.notify_all();
+    }
   }
 }
 
@@ -270,7 +290,12 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     if (rc) return rc;
     p->sync_slot = (char*)slot;
     p->sync_n = n;
-    p->sync_left.store(n, std::memory_order_relaxed);
+    // parts of at least 128 rows (below that a launch costs more than it hides)
+    p->sync_parts = std::max(1, std::min(p->max_parts, n / 128));
+    p->sync_part_rows = (n + p->sync_parts - 1) / p->sync_parts;
+    p->sync_parts = (n + p->sync_part_rows - 1) / p->sync_part_rows;
+    for (int part = 0; part < p->sync_parts; ++part)
+      p->sync_left[part].v.store(std::min(p->sync_part_rows, n - part * p->sync_part_rows), std::memory_order_relaxed);
     ++p->sync_sent;
   }
   const uint64_t t = p->q_tail.load(std::memory_order_relaxed);  // senders are serialised by smu
@@ -319,6 +344,7 @@ int ep_ygo_pool_create(const ep_ygo_config* cfg, const ep_ygo_engine* engine, in
   p->ring_cap = 2 * (uint64_t)num_envs + 16;  // action_buffer_queue.h: 2 * num_envs
   p->ring.reset(new Cell[p->ring_cap]);
   if (const char* e = getenv("EP_YGO_POOL_TRACE")) p->trace = atoi(e) != 0;
+  if (const char* e = getenv("EP_YGO_POOL_PARTS")) p->max_parts = std::max(1, std::min((int)ep_ygo_pool::kMaxParts, atoi(e)));
   if (const char* e = getenv("EP_YGO_POOL_SPIN")) p->spin_pauses = std::max(0, atoi(e));
   const unsigned hw = usable_cpus();
   // async_envpool.h:113-115: min(batch, hardware_concurrency). A sync pool's receiving thread steps envs

@@ -220,6 +220,14 @@ int64_t ep_ygo_record_used_bytes(const ep_ygo_config* cfg, const void* record);
  * else in flight the kernel reads the slot in place (one launch); a batch committed behind another
  * one is moved by the copy engine under that one's kernel. */
 int ep_ygo_commit_slot_packed(ep_ygo_encoder* enc, int32_t n, const uint32_t* offsets, int64_t used_bytes);
+/* ep_ygo_commit_slot in parts, for producers that finish a batch's rows in stages: rows
+ * [row0, row0 + n_rows) of the slot from ep_ygo_acquire_slot are complete (fixed stride, row i at
+ * i * stride) and may be encoded now, while the other rows of the batch of n_total are still being
+ * written. Parts may come from any thread, in any order, each row once; the call that brings the
+ * parts to n_total rows sets *completed = 1 and the batch is then collected like any other. The
+ * StateBuffer of the reference fills row by row in the same way (state_buffer.h:79-129); there the
+ * rows are final observations, here each part's encode runs under the emission of the rest. */
+int ep_ygo_commit_slot_rows(ep_ygo_encoder* enc, int32_t row0, int32_t n_rows, int32_t n_total, int32_t* completed);
 /* Counters of the arrival-ordered ring since ep_ygo_async_begin: the time producer threads spent
  * waiting for a free slot (the only place where the GPU side can hold the duel threads up), the
  * records handed out and the batches received. Any pointer may be NULL. */

@@ -457,3 +457,39 @@ def test_corrupted_records_do_not_disturb_their_neighbours(monkeypatch):
   from tools import ygo_record_fuzz
   monkeypatch.setenv("FUZZ_SEED", "3")
   ygo_record_fuzz.main(rounds=4)
+
+
+def test_commit_slot_in_parts():
+  """ep_ygo_commit_slot_rows: a batch handed to the encoder as parts of consecutive rows, in any order
+  (each part's encode starts at once); the call that completes the batch says so; the result equals the
+  whole-slot commit's. Zero-copy and staged."""
+  import ctypes as C
+
+  from envpool_amd import capi
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  n = 700
+  cfg = capi_ygo.default_config(max_batch=1024, ring_depth=3)
+  table = ygo_synth.make_table(1000, seed=0)
+  sb = ygo_synth.SynthBatch(cfg, table, n, seed=33)
+  want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
+  rows = np.nonzero(status == 0)[0]
+  recs, _ = capi_ygo.emit_records(cfg, sb.raw, n)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  L = capi_ygo.lib()
+  done = C.c_int32(0)
+  for zero_copy in (1, 0):
+    capi._check(L.ep_ygo_set_zero_copy(enc.handle, zero_copy))
+    slot = C.c_void_p()
+    capi._check(L.ep_ygo_acquire_slot(enc.handle, C.byref(slot)))
+    C.memmove(slot.value, recs.ctypes.data, recs.nbytes)
+    parts = [(300, 150), (0, 300), (650, 50), (450, 200)]   # out of order
+    for i, (r0, cnt) in enumerate(parts):
+      capi._check(L.ep_ygo_commit_slot_rows(enc.handle, r0, cnt, n, C.byref(done)))
+      assert done.value == (1 if i == len(parts) - 1 else 0)
+      if i == 1:  # a row twice, a part past the end, a whole-slot commit in between: refused
+        assert L.ep_ygo_commit_slot_rows(enc.handle, 0, 300, n, C.byref(done)) == capi.EP_ERR_INVALID
+        assert L.ep_ygo_commit_slot_rows(enc.handle, 690, 20, n, C.byref(done)) == capi.EP_ERR_INVALID
+        assert L.ep_ygo_commit_slot(enc.handle, n) == capi.EP_ERR_INVALID
+    _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, f"commit_slot_rows zero_copy={zero_copy}")
+  enc.close()

@@ -42,6 +42,7 @@ struct ep_ygo_encoder {
   std::vector<char> slot;
   std::vector<MockRec> committed;
   bool has_committed = false;
+  int rows_in = 0;
   // what the last recv / collect handed out (the views stay valid until the next one)
   std::vector<int32_t> out_ids, out_elapsed, out_action;
   std::vector<uint8_t> out_done;
@@ -143,6 +144,15 @@ int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {  // fixed stride: row i a
   e->has_committed = true;
   return EP_OK;
 }
+int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int32_t n_total, int32_t* completed) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->rows_in == 0) e->committed.assign((size_t)n_total, MockRec{});
+  for (int i = row0; i < row0 + n_rows; ++i) memcpy(&e->committed[(size_t)i], e->slot.data() + (size_t)i * kStride, sizeof(MockRec));
+  e->rows_in += n_rows;
+  *completed = 0;
+  if (e->rows_in == n_total) { e->rows_in = 0; e->has_committed = true; *completed = 1; }
+  return EP_OK;
+}
 int ep_ygo_collect(ep_ygo_encoder* e, int32_t, ep_batch* out) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->has_committed) return EP_ERR_WOULD_BLOCK;
@@ -181,8 +191,8 @@ int main() {
   memset(&cfg, 0, sizeof(cfg));
   cfg.max_cards = 75; cfg.max_options = 16; cfg.n_history_actions = 16; cfg.max_multi_select = 5;
   std::mt19937 rng(1);
-  {  // sync pool: rows in sent order, partial sends, forced resets, an engine failure
-    const int N = 64;
+  for (const int N : {64, 600}) {  // sync pool: rows in sent order, partial sends, forced resets, an engine failure
+    // (600 envs: the batch goes to the encoder in up to four parts, ep_ygo_commit_slot_rows)
     Engine g{std::vector<int64_t>(N, 0), std::vector<int32_t>(N, 0)};
     ep_ygo_engine eng{&g, eng_reset, eng_step};
     ep_ygo_pool* p = nullptr;
@@ -191,7 +201,7 @@ int main() {
     for (int i = 0; i < N; ++i) ids[i] = i;
     std::vector<int32_t> cur(N, -1);
     std::vector<char> done(N, 1);
-    for (int it = 0; it < 300; ++it) {
+    for (int it = 0; it < (N > 64 ? 120 : 300); ++it) {
       std::shuffle(ids.begin(), ids.end(), rng);
       const int n = it % 3 ? N : 1 + (int)(rng() % N);
       const bool reset = it % 17 == 0;
