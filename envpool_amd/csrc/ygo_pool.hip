@@ -135,6 +135,7 @@ inline int64_t now_ns() {
 void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& scratch) {
   const size_t stride = (size_t)p->stride;
   if (!p->is_sync && scratch.size() < stride) scratch.resize(stride);
+  int64_t v_engine = 0, v_emit = 0;  // trace: this visit's sums, added to the pool's once per visit
   for (int i = 0; i < k; ++i) {
     const Slice& s = sl[i];
     uint8_t* const rec = p->is_sync ? (uint8_t*)p->sync_slot + stride * (size_t)s.order : scratch.data();
@@ -159,9 +160,10 @@ void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& sc
     // (a state the emitter cannot parse comes back as its empty observation: the row still arrives)
     if (ep_ygo_emit_record(&p->cfg, &st, rec) != EP_OK) p->emit_refused.store(1, std::memory_order_relaxed);
     e.in_flight.store(0, std::memory_order_release);
-    if (p->trace) { p->t_engine += c1 - c0; p->t_emit += now_ns() - c1; p->t_slices += 1; }
+    if (p->trace) { v_engine += c1 - c0; v_emit += now_ns() - c1; }
     if (!p->is_sync && ep_ygo_put_arrival(p->enc, rec) != EP_OK) p->engine_failed.store(1, std::memory_order_relaxed);
   }
+  if (p->trace) { p->t_engine += v_engine; p->t_emit += v_emit; p->t_slices += k; }
   if (!p->is_sync) return;
   // The batch's set-up is read BEFORE this visit's first count-down: once the last one is done the
   // batch may complete, be received, and the next send rewrite it.
