@@ -55,7 +55,7 @@ SYMBOLS = [
   "ep_ygo_ring_stats", "ep_ygo_set_packed", "ep_ygo_emit_arrival", "ep_ygo_put_arrival", "ep_ygo_record_used_bytes",
   "ep_ygo_commit_slot_packed", "ep_ygo_commit_slot_rows", "ep_ygo_emit_records_packed",
   "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
-  "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads", "ep_ygo_pool_set_env_id_offset",
+  "ep_ygo_last_env_ids", "ep_ygo_pool_last_env_ids", "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads", "ep_ygo_pool_set_env_id_offset",
 ]
 
 # the duel-engine callbacks of ep_ygo_pool_create
@@ -122,6 +122,8 @@ def lib():
     L.ep_ygo_pool_encoder.argtypes = [vp]
     L.ep_ygo_pool_encoder.restype = vp
     L.ep_ygo_pool_num_threads.argtypes = [vp]
+    L.ep_ygo_pool_last_env_ids.argtypes = [vp, vp, vp]
+    L.ep_ygo_last_env_ids.argtypes = [vp, vp, vp]
     L.ep_ygo_pool_set_env_id_offset.argtypes = [vp, i32]
     L.ep_ygo_history_push.argtypes = [C.POINTER(YgoConfig), vp, C.POINTER(i32), i32, C.c_char_p, vp, i32]
     _bound = L
@@ -231,6 +233,11 @@ class YgoPoolC:
   @property
   def encoder_handle(self):
     return C.c_void_p(self._L.ep_ygo_pool_encoder(self._h))
+
+  def last_env_ids(self):
+    ids, n = C.POINTER(C.c_int32)(), C.c_int32(0)
+    capi._check(self._L.ep_ygo_pool_last_env_ids(self._h, C.byref(ids), C.byref(n)))
+    return np.ctypeslib.as_array(ids, shape=(n.value,)).copy()
 
   @property
   def num_threads(self):

@@ -170,6 +170,17 @@ struct YgoPool {
     return py::make_tuple(out, b.num_rows, b.num_rows);
   }
 
+  // info:env_id of the batch received last, from host memory (a copy: the library's array only lives
+  // until the next recv)
+  py::array_t<int32_t> last_env_ids() {
+    const int32_t* ids = nullptr;
+    int32_t n = 0;
+    epy::check(ep_ygo_pool_last_env_ids(pool, &ids, &n));
+    py::array_t<int32_t> out(n);
+    std::memcpy(out.mutable_data(), ids, sizeof(int32_t) * (size_t)n);
+    return out;
+  }
+
   void set_recv_timeout(int64_t ms) { epy::check(ep_ygo_pool_set_recv_timeout(pool, ms)); }
   int num_threads() { return ep_ygo_pool_num_threads(pool); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
@@ -217,6 +228,7 @@ PYBIND11_MODULE(ygopro_envpool, m) {
       .def("_reset", &YgoPool::reset)
       .def("_recv_all", &YgoPool::recv_all)
       .def("_recv_device_all", &YgoPool::recv_device)
+      .def("_last_env_ids", &YgoPool::last_env_ids)
       .def("_set_recv_timeout", &YgoPool::set_recv_timeout)
       .def("_num_threads", &YgoPool::num_threads)
       .def("_handle", &YgoPool::handle)

@@ -62,6 +62,7 @@ struct Slot {
   char* d_out = nullptr;   // all output keys of one batch
   hipEvent_t copied = nullptr, done = nullptr;
   int n = 0;
+  std::unique_ptr<int32_t[]> h_ids;  // arrival-ordered mode: info:env_id of row i, in host memory (ep_ygo_last_env_ids)
   int rows_launched = 0;  // ep_ygo_commit_slot_rows: rows of the batch being filled that are on their way
   bool busy = false;
 };
@@ -109,6 +110,7 @@ struct ep_ygo_encoder {
   std::atomic<bool> a_closing{false};  // ep_ygo_async_end: waiters leave with an error instead of sleeping on
   std::atomic<uint64_t> a_space_wait_ns{0};
   size_t tab_bytes = 0;
+  int a_last_slot = -1;                           // slot of the batch ep_ygo_recv handed out last
   bool a_packed = false;                          // arrival-ordered mode: records packed back to back (ep_ygo_emit_arrival)
   std::unique_ptr<std::atomic<uint32_t>[]> a_bytes;  // [ring] bytes of packed records in the slot    // time producers spent waiting for a free slot (ring full)
 };
@@ -691,6 +693,9 @@ int ep_ygo_async_begin(ep_ygo_encoder* e, int32_t batch_size) {
   e->a_bytes.reset(new std::atomic<uint32_t>[e->slots.size()]);
   for (size_t i = 0; i < e->slots.size(); ++i) { e->a_done[i].store(0); e->a_bytes[i].store(0); }
   e->a_packed = false;
+  e->a_last_slot = -1;
+  for (auto& sl : e->slots)
+    if (!sl.h_ids) sl.h_ids.reset(new int32_t[(size_t)e->cfg.max_batch]());
   e->a_committed.assign(e->slots.size(), 0);
   e->a_closing.store(false);
   return EP_OK;
@@ -742,6 +747,10 @@ int ep_ygo_record_done(ep_ygo_encoder* e, uint64_t ticket) {
   const uint64_t depth = e->slots.size();
   const uint64_t bi = ticket / (uint64_t)B;
   const int si = (int)(bi % depth);
+  if (!e->a_packed) {  // (packed rows: put_arrival has the record at hand)
+    const uint64_t row = ticket % (uint64_t)B;
+    e->slots[si].h_ids[row] = reinterpret_cast<const ygo_header*>(e->slots[si].h_rec + row * (uint64_t)e->lay.stride)->env_id;
+  }
   // acq_rel: the thread that sees the B-th completion also sees every record of the batch
   if (e->a_done[si].fetch_add(1, std::memory_order_acq_rel) + 1 != B) return EP_OK;
   e->a_done[si].store(0, std::memory_order_relaxed);
@@ -805,6 +814,7 @@ int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
   e->collect_idx = e->submit_idx = 0;
   if (rc) return rc;
   e->a_committed[si] = 0;
+  e->a_last_slot = si;
   const bool bad = e->h_err[si] != 0;
   e->h_err[si] = 0;
   e->a_recv.store(bi + 1, std::memory_order_release);
@@ -813,6 +823,17 @@ int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
     return fail(EP_ERR_ACTION_CHECK,
                 "a record hit a condition on which the reference throws (unknown card code / attribute / race / "
                 "position / phase, a spec that is not on the field, or more rows than max_cards)");
+  return EP_OK;
+}
+
+int ep_ygo_last_env_ids(ep_ygo_encoder* e, const int32_t** ids, int32_t* n) {
+  if (!e || !ids || !n) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->async_B) return fail(EP_ERR_INVALID, "arrival-ordered mode only (ep_ygo_async_begin): in submit / collect mode the caller placed the rows itself");
+  if (e->a_last_slot < 0) return fail(EP_ERR_WOULD_BLOCK, "no batch has been received yet");
+  // (the slot of the batch received last is not refilled before the next ep_ygo_recv: ep_ygo_alloc_record)
+  *ids = e->slots[(size_t)e->a_last_slot].h_ids.get();
+  *n = e->async_B;
   return EP_OK;
 }
 
@@ -844,6 +865,7 @@ static int put_arrival(ep_ygo_encoder* e, const void* record, int64_t used) {
   Slot& s = e->slots[si];
   memcpy(s.h_rec + off, record, (size_t)used);
   reinterpret_cast<uint32_t*>(s.h_tab)[ticket % (uint64_t)B] = off;
+  s.h_ids[ticket % (uint64_t)B] = reinterpret_cast<const ygo_header*>(record)->env_id;
   return ep_ygo_record_done(e, ticket);
 }
 

@@ -100,6 +100,9 @@ struct ep_ygo_pool {
   uint64_t sync_sent = 0, sync_committed = 0, sync_received = 0;  // (one batch at a time: sync_sent names the one being filled)
   char* sync_slot = nullptr;
   int sync_n = 0;
+  std::vector<int32_t> sync_ids[2];  // the ids of the last two sends ([sync_sent & 1]): ep_ygo_pool_last_env_ids
+  const int32_t* last_ids = nullptr;
+  int last_ids_n = 0;
   // The batch goes to the encoder in up to kMaxParts parts of consecutive rows, each as soon as its
   // rows are emitted: slices are claimed in sent order, so the early rows are done while the late
   // ones are still being stepped, and their encode (launch, PCIe reads, kernel) runs under that.
@@ -299,6 +302,7 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     for (int part = 0; part < p->sync_parts; ++part)
       p->sync_left[part].v.store(std::min(p->sync_part_rows, n - part * p->sync_part_rows), std::memory_order_relaxed);
     ++p->sync_sent;
+    p->sync_ids[p->sync_sent & 1].assign(env_id, env_id + n);
   }
   const uint64_t t = p->q_tail.load(std::memory_order_relaxed);  // senders are serialised by smu
   for (int i = 0; i < n; ++i) {
@@ -438,6 +442,8 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
     rc = ep_ygo_collect(p->enc, mem_out, out);
     std::lock_guard<std::mutex> lk(p->smu);
     p->sync_received = p->sync_sent;
+    p->last_ids = p->sync_ids[p->sync_sent & 1].data();
+    p->last_ids_n = p->sync_n;
     if (p->trace) { p->t_drain += r1 - r0; p->t_wait += r2 - r1; p->t_collect += now_ns() - r2; ++p->n_recv; }
   } else {
     rc = ep_ygo_recv(p->enc, mem_out, out);
@@ -458,6 +464,16 @@ int ep_ygo_pool_set_env_id_offset(ep_ygo_pool* p, int32_t env_id_offset) {
   for (int i = 0; i < p->N; ++i)
     if (p->envs[i].current_step != -1) return fail(EP_ERR_INVALID, "set the env id offset before the first send / reset");
   p->env_off = env_id_offset;
+  return EP_OK;
+}
+
+int ep_ygo_pool_last_env_ids(ep_ygo_pool* p, const int32_t** ids, int32_t* n) {
+  if (!p || !ids || !n) return fail(EP_ERR_INVALID, "null argument");
+  if (!p->is_sync) return ep_ygo_last_env_ids(p->enc, ids, n);  // rows in arrival order: the ring noted them
+  std::lock_guard<std::mutex> lk(p->smu);
+  if (!p->last_ids) return fail(EP_ERR_WOULD_BLOCK, "no batch has been received yet");
+  *ids = p->last_ids;  // rows in sent order: the ids of that send
+  *n = p->last_ids_n;
   return EP_OK;
 }
 

@@ -165,6 +165,13 @@ class _YGOProEnvPool(_YGOProNativePool):
     self.last_h_card_ids, self.last_action_mask = descs[16], descs[17]
     return descs[:16], rows, prows
 
+  @property
+  def last_env_ids(self) -> np.ndarray:
+    """Additive: `info:env_id` of the batch received last as a host array, from host memory (the
+    pool noted the ids as the rows arrived): `env.send(actions, env.last_env_ids)` after a
+    `recv_torch` needs no read-back of the batch's own `info:env_id` from the device."""
+    return self._last_env_ids()
+
 
 from ..python.api import py_env, raw_env  # noqa: E402
 

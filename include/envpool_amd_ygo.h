@@ -212,6 +212,11 @@ int ep_ygo_set_recv_timeout(ep_ygo_encoder* enc, int64_t milliseconds);
  * Batches are received with ep_ygo_recv. Results are identical in every form. */
 int ep_ygo_set_packed(ep_ygo_encoder* enc, int32_t enabled);
 int ep_ygo_put_arrival(ep_ygo_encoder* enc, const void* record);
+/* Arrival-ordered mode: info:env_id of the batch ep_ygo_recv handed out last, row by row, in HOST
+ * memory (the producers noted them as their rows arrived), valid until the next ep_ygo_recv. For a
+ * consumer that keeps the batch on the device (EP_MEM_DEVICE) and only needs to know whom to send the
+ * next actions to. No counterpart in the reference (its batches are host memory). */
+int ep_ygo_last_env_ids(ep_ygo_encoder* enc, const int32_t** ids, int32_t* n);
 int64_t ep_ygo_record_used_bytes(const ep_ygo_config* cfg, const void* record);
 /* The packed form for ONE producer (submit / collect mode): the caller fills the slot it got from
  * ep_ygo_acquire_slot with n records back to back (record i at byte offsets[i], 16-byte aligned,
@@ -334,6 +339,10 @@ int ep_ygo_pool_set_recv_timeout(ep_ygo_pool* pool, int64_t milliseconds); /* as
  * 1024 per pool): this pool owns the global ids [offset, offset + num_envs). send / reset take global
  * ids, the callbacks get global ids, info:env_id is global. Before the first send / reset. */
 int ep_ygo_pool_set_env_id_offset(ep_ygo_pool* pool, int32_t env_id_offset);
+/* info:env_id of the batch ep_ygo_pool_recv handed out last (global ids), in host memory, valid until
+ * the next ep_ygo_pool_recv: what the next ep_ygo_pool_send of an async actor loop takes, without
+ * reading the batch's own info:env_id back from the device. No counterpart in the reference. */
+int ep_ygo_pool_last_env_ids(ep_ygo_pool* pool, const int32_t** ids, int32_t* n);
 ep_ygo_encoder* ep_ygo_pool_encoder(ep_ygo_pool* pool); /* for ep_ygo_set_timing / ep_ygo_ring_stats */
 int32_t ep_ygo_pool_num_threads(ep_ygo_pool* pool);
 

@@ -54,7 +54,7 @@ def test_sync_pool_rows_in_sent_order(threads):
       pool.send(sel, act)
       raws = [model.advance(int(e), int(a)) for e, a in zip(sel, act)]
     out = pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
-    assert out[0].tolist() == sel.tolist()
+    assert out[0].tolist() == sel.tolist() and pool.last_env_ids().tolist() == sel.tolist()
     want, status = _expect_rows(cfg, table, raws)
     for j in range(sel.size):
       if status[j] == 0:
@@ -101,6 +101,7 @@ def test_async_pool_config5_shape(threads):
     out = pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
     got_ids = out[0]
     assert got_ids.shape[0] == B and len(set(got_ids.tolist())) == B
+    assert pool.last_env_ids().tolist() == got_ids.tolist()   # the host-side note of who arrived, row by row
     raws = [expect.pop(int(e)) for e in got_ids]
     want, status = _expect_rows(cfg, table, raws)
     for j in range(B):
@@ -210,6 +211,7 @@ def test_make_ygopro_with_init_module():
     env.send(np.full(N, 3, np.int32))
     obs_t, rew_t, term_t, trunc_t, info_t = env.recv_torch()
     assert obs_t["cards_"].is_cuda and tuple(obs_t["cards_"].shape) == (N, 150, 39)
+    assert env.last_env_ids.tolist() == info_t["env_id"].cpu().tolist()
     assert (info_t["win_reason"] == 3).all().item() and info_t["env_id"].cpu().tolist() == list(range(N))
     m = info_t["action_mask"]
     assert m.is_cuda and tuple(m.shape) == (N, 16)

@@ -260,8 +260,9 @@ def run_config5(device=0, threads_list=(1, 4, 12, 16), n_envs=1024, batch=512, s
 def run_config5_pool(device=0, threads_list=(4, 16), n_envs=1024, batch=512, batches=120, engine_us=None):
   """BASELINE config 5 per GPU as a POOL (ep_ygo_pool, envpool_amd/csrc/ygo_pool.hip): async mode,
   1024 envs, batches of 512, the stand-in duel engine behind the ep_ygo_engine callbacks. The loop
-  is the user's: recv a batch (device views), send an action for every env in it (read back from
-  the batch's info:env_id, 2 KiB). Reports batches/s per worker-thread count."""
+  is the user's: recv a batch (device views), send an action for every env in it (whose ids the
+  pool hands over from host memory, ep_ygo_pool_last_env_ids; EP_YGO_IDS_FROM_DEVICE=1: read back
+  from the batch's info:env_id instead, 2 KiB). Reports batches/s per worker-thread count."""
   import numpy as np
 
   from envpool_amd import capi, capi_ygo
@@ -288,10 +289,17 @@ def run_config5_pool(device=0, threads_list=(4, 16), n_envs=1024, batch=512, bat
     b = capi.Batch()
     pool.reset(ids)
 
+    from_device = os.environ.get("EP_YGO_IDS_FROM_DEVICE") == "1"
+    idp, idn = C.POINTER(C.c_int32)(), C.c_int32(0)
+
     def one():
       assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
-      assert hip.hipMemcpy(got.ctypes.data, b.arrays[0].data, 4 * batch, 2) == 0  # 2 = device to host
-      assert L.ep_ygo_pool_send(h, batch, got.ctypes.data, act.ctypes.data) == 0
+      if from_device:
+        assert hip.hipMemcpy(got.ctypes.data, b.arrays[0].data, 4 * batch, 2) == 0  # 2 = device to host
+        assert L.ep_ygo_pool_send(h, batch, got.ctypes.data, act.ctypes.data) == 0
+      else:
+        assert L.ep_ygo_pool_last_env_ids(h, C.byref(idp), C.byref(idn)) == 0 and idn.value == batch
+        assert L.ep_ygo_pool_send(h, batch, idp, act.ctypes.data) == 0
     for _ in range(10):
       one()
     t0 = time.perf_counter()

@@ -153,6 +153,7 @@ int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int
   if (e->rows_in == n_total) { e->rows_in = 0; e->has_committed = true; *completed = 1; }
   return EP_OK;
 }
+int ep_ygo_last_env_ids(ep_ygo_encoder* e, const int32_t** ids, int32_t* n) { std::lock_guard<std::mutex> lk(e->mu); *ids = e->out_ids.data(); *n = (int32_t)e->out_ids.size(); return EP_OK; }
 int ep_ygo_collect(ep_ygo_encoder* e, int32_t, ep_batch* out) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->has_committed) return EP_ERR_WOULD_BLOCK;
