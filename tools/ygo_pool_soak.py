@@ -80,6 +80,7 @@ def main(total=int(os.environ.get("SOAK_ROWS", "400000"))):
           pool.send(sel, act)
           raws = [model.advance(int(e), int(a)) for e, a in zip(sel, act)]
         out = pool.recv(allow=ok_rc)
+        assert pool.last_env_ids().tolist() == sel.tolist(), (tag, "last_env_ids")
         rows += compare(tag, cfg, table, out, raws, sel)
     else:
       pending = {}
@@ -94,6 +95,7 @@ def main(total=int(os.environ.get("SOAK_ROWS", "400000"))):
         got = out[0]
         in_ring -= B
         assert got.shape[0] == B and len(set(got.tolist())) == B, (tag, "batch shape")
+        assert pool.last_env_ids().tolist() == got.tolist(), (tag, "last_env_ids")
         rows += compare(tag, cfg, table, out, [pending.pop(int(e)) for e in got], got)
         # send back a random part of what arrived (the rest of those envs idle from here on)
         back = got[: int(rng.integers(0, B + 1))] if rng.integers(0, 3) == 0 else got
