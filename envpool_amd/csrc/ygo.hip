@@ -63,6 +63,7 @@ struct Slot {
   hipEvent_t copied = nullptr, done = nullptr;
   int n = 0;
   std::unique_ptr<int32_t[]> h_ids;  // arrival-ordered mode: info:env_id of row i, in host memory (ep_ygo_last_env_ids)
+  void* out_blk = nullptr;  // host-output mode: the pinned block this batch's kernels write their rows into
   int rows_launched = 0;  // ep_ygo_commit_slot_rows: rows of the batch being filled that are on their way
   bool busy = false;
 };
@@ -94,6 +95,10 @@ struct ep_ygo_encoder {
   std::recursive_mutex featurize_mu;  // ep_ygo_featurize = submit + collect, atomically with respect to the other submitters
   std::shared_ptr<epc::HostBlocks> blocks;
   bool timing = false;
+  // Where a batch's kernels write: the slot's device arrays, or - when the consumer took the batch
+  // before this one as host arrays - straight into the pinned host block that recv / collect will
+  // hand out (over PCIe, under the kernel: no device-to-host copy afterwards). Follows the consumer.
+  bool host_out = false;
   bool zero_copy = true;  // the kernel reads the pinned slot over PCIe itself (no staging copy); EP_YGO_ZERO_COPY=0: stage through d_rec
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
   double timed_total_us = 0;
@@ -160,7 +165,18 @@ int launch(ep_ygo_encoder* e, const char* d_records, int n, int slot, bool lean_
   a.max_episode_steps = e->cfg.max_episode_steps;
   a.lean_fetch = lean_fetch ? 1 : 0;
   a.cv = ygk::carve(e->cfg.max_cards, e->cfg.max_options, e->cfg.n_history_actions, e->cfg.max_multi_select);
-  out_ptrs(e, e->slots[slot].d_out, &a.out);
+  {
+    Slot& sl = e->slots[slot];
+    if (e->host_out && !sl.out_blk)
+      if (int rc = epc::take_block(e->blocks, &sl.out_blk)) return rc;
+    char* base = sl.d_out;
+    if (sl.out_blk) {  // (set by the batch's first launch: every part of a batch writes to one place)
+      void* dev_view = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev_view, sl.out_blk, 0));
+      base = (char*)dev_view;
+    }
+    out_ptrs(e, base, &a.out);
+  }
   a.err = e->d_err + slot;
   a.stamps = e->d_stamps;
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -189,7 +205,19 @@ int describe(ep_ygo_encoder* e, int slot, int32_t mem_out, ep_batch* out) {
   out->num_player_rows = n;
   out->seq = e->collect_idx;
   char* base = s.d_out;
-  if (mem_out == EP_MEM_HOST) {
+  e->host_out = mem_out == EP_MEM_HOST;  // the batches launched from now on are written where this consumer reads
+  if (s.out_blk && mem_out == EP_MEM_HOST) {
+    // the kernels wrote the block themselves (and the caller has waited for them)
+    out->owner = new epc::HostBlockOwner{e->blocks, s.out_blk};
+    base = (char*)s.out_blk;
+    s.out_blk = nullptr;
+  } else if (s.out_blk) {
+    // written for a host consumer, wanted as device views: the block goes to the slot's device arrays
+    HIP_TRY(hipMemcpyAsync(s.d_out, s.out_blk, e->out_bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    epc::give_block(e->blocks, s.out_blk);
+    s.out_blk = nullptr;
+  } else if (mem_out == EP_MEM_HOST) {
     void* blk = nullptr;
     int rc = epc::take_block(e->blocks, &blk);
     if (rc) return rc;
@@ -321,6 +349,7 @@ int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
   }
 #endif
   for (auto& s : e->slots) {
+    if (s.out_blk) epc::give_block(e->blocks, s.out_blk);
     if (s.h_tab) (void)hipHostFree(s.h_tab);
     (void)hipFree(s.d_tab);
     (void)hipFree(s.d_out);
