@@ -493,3 +493,56 @@ def test_commit_slot_in_parts():
         assert L.ep_ygo_commit_slot(enc.handle, n) == capi.EP_ERR_INVALID
     _compare(enc.collect(allow=(capi.EP_ERR_ACTION_CHECK,)), want, rows, f"commit_slot_rows zero_copy={zero_copy}")
   enc.close()
+
+
+def test_results_follow_the_consumer_host_or_device():
+  """Where a batch's rows are written follows the kind of the last collect (host arrays: the kernels
+  write the pinned block that is handed out; device views: the slot's device arrays), and a batch
+  written for the other kind is carried across: every order of host / device collects, with several
+  batches in flight, gives the oracle's rows."""
+  import ctypes as C
+
+  import torch
+
+  from envpool_amd import capi, interop
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  n = 300
+  cfg = capi_ygo.default_config(max_batch=512, ring_depth=4)
+  table = ygo_synth.make_table(1000, seed=0)
+  enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
+  L = capi_ygo.lib()
+  batches = []
+  for k in range(3):
+    sb = ygo_synth.SynthBatch(cfg, table, n, seed=50 + k)
+    want, status = ygo_oracle.write_batch(cfg, table, sb.raw, n)
+    recs, _ = capi_ygo.emit_records(cfg, sb.raw, n)
+    batches.append((recs, want, np.nonzero(status == 0)[0]))
+
+  def collect(mem):
+    b = capi.Batch()
+    rc = L.ep_ygo_collect(enc.handle, mem, C.byref(b))
+    assert rc in (0, capi.EP_ERR_ACTION_CHECK)
+    if mem == capi.EP_MEM_HOST:
+      out = [np.array(a) for a in capi.batch_to_numpy(b)]
+      L.ep_batch_release(C.byref(b))
+      return out
+    out = []
+    for d in capi.batch_to_descs(b):
+      ptr, shape, ts = d
+      if ts == "<u2":   # torch has no uint16 views on this version: read the two bytes apart
+        t = interop.as_torch((ptr, tuple(shape) + (2,), "|u1"), device="cuda:0").cpu().numpy()
+        out.append(t.view(np.uint16).reshape(shape))
+      else:
+        out.append(interop.as_torch(d, device="cuda:0").cpu().numpy())
+    return out
+
+  H, D = capi.EP_MEM_HOST, capi.EP_MEM_DEVICE
+  step = 0
+  for pattern in ([H, H, D], [D, D, H], [H, D, H], [D, H, D], [H, H, H], [D, D, D]):
+    for recs, _, _ in batches:   # three in flight, all launched under the mode the LAST collect left
+      enc.submit(recs)
+    for mem, (_, want, rows) in zip(pattern, batches):
+      _compare(collect(mem), want, rows, f"pattern {pattern} step {step}")
+      step += 1
+  enc.close()
