@@ -343,10 +343,13 @@ def run_config3_pool(device=0, threads_list=(4, 0), n_envs=1024, steps=150, engi
     pool.reset(ids)
     assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
     ts = []
+    mem = capi.EP_MEM_HOST if os.environ.get("EP_YGO_HOST_OUT") == "1" else capi.EP_MEM_DEVICE  # host arrays out: 6.9 MB per step over PCIe
     for i in range(steps + 20):
       t0 = time.perf_counter()
       assert L.ep_ygo_pool_send(h, n_envs, ids.ctypes.data, act.ctypes.data) == 0
-      assert L.ep_ygo_pool_recv(h, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+      assert L.ep_ygo_pool_recv(h, mem, C.byref(b)) in ok
+      if mem == capi.EP_MEM_HOST:
+        L.ep_batch_release(C.byref(b))
       if i >= 20:
         ts.append(time.perf_counter() - t0)
     ts.sort()
