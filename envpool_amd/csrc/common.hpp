@@ -49,6 +49,10 @@ struct HostBlockOwner {
   void* ptr;
 };
 
+// An argument that says where the caller's memory is must be one of the two kinds: anything else
+// would be read as one of them and the pointers with it.
+inline bool bad_mem(int32_t mem) { return mem != EP_MEM_HOST && mem != EP_MEM_DEVICE; }
+
 inline int take_block(const std::shared_ptr<HostBlocks>& hb, void** out) {
   void* blk = nullptr;
   {

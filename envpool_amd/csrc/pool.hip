@@ -848,6 +848,7 @@ int ep_pool_destroy(ep_pool* p) {
 
 int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   if (!p || (!env_ids && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad reset arguments");
+  if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
@@ -876,6 +877,7 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
 int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims,
                  int32_t mem) {
   if (!p || !arrays || !leading_dims) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   if (n_arrays != 5)
     return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays in _action_keys order, got %d", n_arrays);
   const int64_t n = leading_dims[0], np_rows = leading_dims[1];
@@ -1246,6 +1248,7 @@ extern "C" {
 
 int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
@@ -1263,6 +1266,7 @@ int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
 
 int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
+  if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::unique_lock<std::mutex> lk(p->mu);
   int rc = set_device(p);
   if (rc) return rc;
@@ -1420,6 +1424,7 @@ int ep_pool_sync(ep_pool* p) {
 }
 
 int ep_pool_episode_stats(ep_pool* p, float* fin_return, int32_t* fin_length, int32_t* ep_count, int32_t mem) {
+  if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->mu);
   int rc = set_device(p);

@@ -630,6 +630,7 @@ int ep_ygo_submit(ep_ygo_encoder* e, const void* host_records, int32_t n) {
 
 int ep_ygo_collect(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
   if (!e || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem_out)) return fail(EP_ERR_INVALID, "mem_out = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem_out);
   std::lock_guard<std::mutex> lk(e->mu);
   if (e->collect_idx == e->submit_idx) return fail(EP_ERR_WOULD_BLOCK, "nothing submitted");
   HIP_TRY(hipSetDevice(e->device));
@@ -651,6 +652,8 @@ int ep_ygo_collect(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
 
 int ep_ygo_featurize(ep_ygo_encoder* e, const void* records, int32_t n, int32_t mem_in, int32_t mem_out, ep_batch* out) {
   if (!e || !out || (!records && n > 0)) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem_in) || epc::bad_mem(mem_out))
+    return fail(EP_ERR_INVALID, "mem_in = %d / mem_out = %d: each must be EP_MEM_HOST or EP_MEM_DEVICE", mem_in, mem_out);
   if (n < 0 || n > e->cfg.max_batch) return fail(EP_ERR_INVALID, "n = %d outside [0, max_batch = %d]", n, e->cfg.max_batch);
   // submit + collect as ONE operation: collect hands out the OLDEST batch in flight, so with
   // another batch still in flight (or another thread submitting in between) the caller would get
@@ -820,6 +823,7 @@ int ep_ygo_record_done(ep_ygo_encoder* e, uint64_t ticket) {
 
 int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
   if (!e || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem_out)) return fail(EP_ERR_INVALID, "mem_out = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem_out);
   if (!e->async_B) return fail(EP_ERR_INVALID, "call ep_ygo_async_begin first");
   std::unique_lock<std::mutex> lk(e->mu);
   const uint64_t depth = e->slots.size();

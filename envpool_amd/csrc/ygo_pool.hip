@@ -409,6 +409,7 @@ int ep_ygo_pool_set_recv_timeout(ep_ygo_pool* p, int64_t milliseconds) {
 
 int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (epc::bad_mem(mem_out)) return fail(EP_ERR_INVALID, "mem_out = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem_out);
   int rc;
   if (p->is_sync) {
     {

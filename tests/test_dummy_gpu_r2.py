@@ -389,3 +389,12 @@ def test_host_and_device_sends_into_one_batch(host_first):
     sel = np.asarray(want[0]).astype(np.int32)
     g._send(dummy_action(sel)); o._send(dummy_action(sel))
   g.close()
+
+
+def test_refused_calls_leave_the_pool_as_it_was(monkeypatch):
+  """tools/dummy_abi_fuzz.py, a few rounds: wrong array counts, null pointers, disagreeing / negative /
+  oversized dims, unknown memory kinds, rollouts that do not fit - each refused, and the valid steps
+  around them still equal the oracle's."""
+  from tools import dummy_abi_fuzz
+  monkeypatch.setenv("FUZZ_SEED", "4")
+  dummy_abi_fuzz.main(rounds=6)

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""GPU box: the Dummy C ABI under calls it must refuse - wrong array counts, null pointers, dims that
+disagree / are negative / exceed the pool, unknown memory kinds, rollouts that do not fit, resets of
+envs the pool does not own - interleaved with valid lockstep steps that are compared with the
+oracle: a refused call must leave the pool exactly as it was. Pointers that are passed are always
+valid (a wild pointer is the caller's); what is fuzzed is everything the library can check."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(rounds=int(os.environ.get("FUZZ_ROUNDS", "30"))):
+  from envpool_amd import capi
+  from oracle.dummy_oracle import DummyOracle
+
+  rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+  L = capi.lib()
+  L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+  L.hipFree.argtypes = [C.c_void_p]
+  refused = accepted = steps = 0
+  for r in range(rounds):
+    N = int(rng.choice([1, 7, 64, 256, 1000, 4096]))
+    sync = bool(rng.integers(0, 2)) or N == 1
+    B = N if sync else int(rng.integers(1, N))
+    seed = int(rng.integers(1, 50))
+    pool = capi.DummyPoolC(num_envs=N, batch_size=B, seed=seed)
+    pool.set_recv_timeout(20000)
+    orc = DummyOracle(num_envs=N, batch_size=B, seed=seed)
+    h = pool.handle
+    ids = np.arange(N, dtype=np.int32)
+    la = np.full((N, 6), 1.5)
+    zeros = np.zeros(N, np.int32)
+    big = np.zeros(4 * N + 8, np.int32)
+    dev = C.c_void_p()
+    assert L.hipMalloc(C.byref(dev), 64 * (N + 8)) == 0  # a valid device buffer for the device-memory refusals
+
+    def valid_step(first=False):
+      # one batch received and compared, then sent back (a batch is always there: everything that
+      # was received has been sent again, and num_envs >= batch_size)
+      nonlocal steps
+      if first:
+        pool._reset(ids); orc._reset(ids)
+      got, want = pool._recv(), orc._recv()
+      for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11):
+        assert np.asarray(got[k]).tobytes() == np.asarray(want[k]).tobytes(), ("after a refused call", r, k)
+      e = np.array(got[0])
+      act = [e, e, la[: e.size], zeros[: e.size], zeros[: e.size]]
+      pool._send(act); orc._send(act)
+      steps += e.size
+
+    def call_send(n_arrays, arrays, dims, mem):
+      ptrs = (C.c_void_p * max(1, len(arrays)))(*arrays) if arrays is not None else None
+      dd = (C.c_int64 * max(1, len(dims)))(*dims) if dims is not None else None
+      return L.ep_pool_send(h, n_arrays, ptrs, dd, mem)
+
+    host = [ids.ctypes.data, ids.ctypes.data, la.ctypes.data, zeros.ctypes.data, zeros.ctypes.data]
+    devp = [dev.value] * 5
+    good = [N] * 5 if sync else [B] * 5
+    menu = [
+      lambda: call_send(int(rng.choice([0, 1, 3, 4, 6, -1, 100])), host, good, capi.EP_MEM_HOST),
+      lambda: call_send(5, None, good, capi.EP_MEM_HOST),
+      lambda: call_send(5, host, None, capi.EP_MEM_HOST),
+      lambda: call_send(5, [0] + host[1:], good, capi.EP_MEM_HOST),
+      lambda: call_send(5, host[:2] + [0] + host[3:], good, capi.EP_MEM_HOST),
+      lambda: call_send(5, host, [good[0], good[0] - 1] + good[2:], capi.EP_MEM_HOST) if good[0] > 1 else 1,  # fewer player rows than envs
+      lambda: call_send(5, host, [good[0], good[1], good[2] - 1 if good[2] > 1 else 2] + good[3:], capi.EP_MEM_HOST),
+      lambda: call_send(5, host, [-1] * 5, capi.EP_MEM_HOST),
+      lambda: call_send(5, [big.ctypes.data] * 2 + [la.ctypes.data] + [big.ctypes.data] * 2, [2 * N + 3] * 5, capi.EP_MEM_HOST),
+      lambda: call_send(5, host, good, int(rng.choice([2, 3, -1, 99]))),
+      lambda: call_send(5, devp, [-5] * 5, capi.EP_MEM_DEVICE),
+      lambda: call_send(5, devp, [2 * N + 1] * 5, capi.EP_MEM_DEVICE),
+      lambda: call_send(5, [0] * 5, good, capi.EP_MEM_DEVICE),
+      lambda: call_send(5, [dev.value, dev.value, dev.value + 4, dev.value, dev.value], good, capi.EP_MEM_DEVICE),  # list_action off its alignment
+      lambda: L.ep_pool_reset(h, ids.ctypes.data, N + 1, capi.EP_MEM_HOST),
+      lambda: L.ep_pool_reset(h, ids.ctypes.data, -3, capi.EP_MEM_HOST),
+      lambda: L.ep_pool_reset(h, None, 1, capi.EP_MEM_HOST),
+      lambda: L.ep_pool_reset(h, (big + N).ctypes.data, 1, capi.EP_MEM_HOST),   # an env id outside the pool
+      lambda: L.ep_pool_reset(h, ids.ctypes.data, 1, 7),
+      lambda: L.ep_pool_recv(h, 5, C.byref(capi.Batch())),
+      lambda: L.ep_pool_recv(h, capi.EP_MEM_HOST, None),
+      lambda: L.ep_pool_checkpoint_restore(h, None),
+      lambda: L.ep_pool_checkpoint_save(h, None),
+    ]
+    def call_rollout(T, n_arrays, arrays, dims, strides):
+      ptrs = (C.c_void_p * 5)(*arrays)
+      return L.ep_pool_rollout(h, T, n_arrays, ptrs, (C.c_int64 * 5)(*dims), (C.c_int64 * 5)(*strides))
+
+    Q = L.ep_pool_ring_depth(h)
+    full = [N] * 5
+    menu += [
+      lambda: call_rollout(0, 5, devp, full, [0] * 5),
+      lambda: call_rollout(Q + 1, 5, devp, full, [0] * 5),
+      lambda: call_rollout(1, 4, devp, full, [0] * 5),
+      lambda: call_rollout(1, 5, devp, [N - 1 if N > 1 else 2] * 5, [0] * 5),
+      lambda: call_rollout(1, 5, devp, full, [N, 0, 0, 0, 0]),            # env_id must not move between steps
+      lambda: call_rollout(1, 5, [0] + devp[1:], full, [0] * 5),
+      lambda: call_rollout(1, 5, [dev.value, dev.value + 2, dev.value, dev.value, dev.value], full, [0] * 5),
+    ]
+    if not sync:
+      menu.append(lambda: call_rollout(1, 5, devp, full, [0] * 5))          # rollouts are for sync pools
+    valid_step(first=True)
+    for it in range(40):
+      if rng.integers(0, 2):
+        which = int(rng.integers(0, len(menu)))
+        rc = menu[which]()
+        assert rc != 0, ("an invalid call was accepted: menu item", which, "pool", N, B, "round", r, it)
+        refused += 1
+      valid_step()
+    pool.close()
+    L.hipFree(dev)
+    print(f"ok {r}: N={N} B={B} refused so far {refused}, env-steps compared {steps}", flush=True)
+  print("dummy ABI fuzz passed:", refused, "calls refused,", steps, "env-steps compared with the oracle")
+
+
+if __name__ == "__main__":
+  main()
