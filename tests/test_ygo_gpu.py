@@ -546,3 +546,12 @@ def test_results_follow_the_consumer_host_or_device():
       _compare(collect(mem), want, rows, f"pattern {pattern} step {step}")
       step += 1
   enc.close()
+
+
+def test_refused_calls_leave_the_encoder_and_the_pool_as_they_were(monkeypatch):
+  """tools/ygo_abi_fuzz.py, a few rounds: null arguments, counts outside the batch, unknown memory
+  kinds, calls of the wrong mode, configs outside the limits - each refused, and the valid encodes and
+  pool steps around them unaffected."""
+  from tools import ygo_abi_fuzz
+  monkeypatch.setenv("FUZZ_SEED", "6")
+  ygo_abi_fuzz.main(rounds=3)
