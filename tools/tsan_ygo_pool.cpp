@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -256,6 +257,62 @@ int main() {
       REQUIRE(ep_ygo_pool_send(p, B, back.data(), act.data()) == EP_OK);
     }
     REQUIRE(ep_ygo_pool_destroy(p) == EP_OK);  // with steps still in flight
+  }
+  {  // async pool, one receiver and TWO sender threads (senders are serialised by the pool,
+     // action_buffer_queue.h:60-68): the receiver deals each batch's envs out to the senders by parity
+    const int N = 256, B = 32;
+    Engine g{std::vector<int64_t>(N, 0), std::vector<int32_t>(N, 0)};
+    ep_ygo_engine eng{&g, eng_reset, eng_step};
+    ep_ygo_pool* p = nullptr;
+    REQUIRE(ep_ygo_pool_create(&cfg, &eng, N, B, 4, -1, nullptr, 0, &p) == EP_OK);
+    std::vector<int32_t> ids(N);
+    for (int i = 0; i < N; ++i) ids[i] = i;
+    REQUIRE(ep_ygo_pool_reset(p, N, ids.data()) == EP_OK);
+    struct Box { std::mutex mu; std::condition_variable cv; std::deque<std::vector<int32_t>> q; bool stop = false; } box[2];
+    std::vector<std::thread> senders;
+    for (int s = 0; s < 2; ++s)
+      senders.emplace_back([&, s] {
+        for (;;) {
+          std::vector<int32_t> mine;
+          {
+            std::unique_lock<std::mutex> lk(box[s].mu);
+            box[s].cv.wait(lk, [&] { return box[s].stop || !box[s].q.empty(); });
+            if (box[s].q.empty()) return;
+            mine = std::move(box[s].q.front());
+            box[s].q.pop_front();
+          }
+          std::vector<int32_t> a(mine.size(), s);
+          if (!mine.empty()) REQUIRE(ep_ygo_pool_send(p, (int32_t)mine.size(), mine.data(), a.data()) == EP_OK);
+        }
+      });
+    std::vector<int32_t> seen(N, 0);
+    for (int it = 0; it < 300; ++it) {
+      ep_batch b;
+      REQUIRE(ep_ygo_pool_recv(p, EP_MEM_HOST, &b) == EP_OK);
+      REQUIRE(b.num_rows == B);
+      const int32_t* got = (const int32_t*)b.arrays[0].data;
+      const int32_t* last = nullptr;
+      int32_t n_last = 0;
+      REQUIRE(ep_ygo_pool_last_env_ids(p, &last, &n_last) == EP_OK && n_last == B);
+      std::vector<int32_t> part[2];
+      for (int j = 0; j < B; ++j) {
+        REQUIRE(last[j] == got[j]);
+        seen[got[j]] += 1;
+        part[got[j] & 1].push_back(got[j]);
+      }
+      for (int s = 0; s < 2; ++s) {
+        std::lock_guard<std::mutex> lk(box[s].mu);
+        box[s].q.push_back(std::move(part[s]));
+        box[s].cv.notify_one();
+      }
+    }
+    for (int s = 0; s < 2; ++s) {
+      std::lock_guard<std::mutex> lk(box[s].mu);
+      box[s].stop = true;
+      box[s].cv.notify_one();
+    }
+    for (auto& th : senders) th.join();
+    REQUIRE(ep_ygo_pool_destroy(p) == EP_OK);
   }
   {  // shutdown with a full ring and nobody receiving
     const int N = 64, B = 8;
