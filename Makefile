@@ -79,7 +79,8 @@ build/sanitize_host: tools/sanitize_host.cpp tools/ygo_synth.c $(HIP_SRCS) $(HIP
 	  $(patsubst $(CSRC)/%.hip,build/san_%.o,$(HIP_SRCS)) build/ygo_synth_san.o -pthread
 
 clean:
-	rm -f $(LIB) $(PYMODS) tools/libygosynth.so
+	rm -f $(LIB) $(PYMODS) tools/libygosynth.so examples/dummy_step_loop tools/launch_floor tools/host_latency
+	rm -rf build
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib pymod oracle synth examples sanitize tsan-pool diag clean
