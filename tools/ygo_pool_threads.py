@@ -34,9 +34,9 @@ def main():
       v = r["by_threads"][str(nt)]
       print(f"threads {nt:3d}: {v['batches_per_s']:8.0f} batches/s  {v['env_steps_per_s']:.3e} env-steps/s", flush=True)
       continue
-    r = bench_ygo.run_config3_pool(threads_list=(nt,), steps=300)
+    r = bench_ygo.run_config3_pool(threads_list=(nt,), steps=300, n_envs=int(os.environ.get("ENVS", "1024")))
     t1 = _throttle()
-    v = r["by_threads"][str(nt)]
+    v = list(r["by_threads"].values())[0]
     print(f"threads {nt:3d} spin {spin:7d}: median {v['us_per_step_median']:7.1f} us/step  throttled periods +{t1[0] - t0[0]}  (+{(t1[1] - t0[1]) / 1e3:.1f} ms)", flush=True)
 
 
