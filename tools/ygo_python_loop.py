@@ -23,7 +23,8 @@ def main():
   import envpool_amd
   from envpool_amd import capi_ygo, ygopro
   from tools import ygo_synth
-  N, B = 1024, 512
+  N = int(os.environ.get("ENVS", "1024"))
+  B = max(1, N // 2)
   table = ygo_synth.make_table(1000, seed=0)
   for mode, bs in (("sync", N), ("async", B)):
     cfg = capi_ygo.default_config(max_batch=bs, ring_depth=0)
