@@ -799,13 +799,14 @@ int ep_ygo_record_done(ep_ygo_encoder* e, uint64_t ticket) {
     st = e->stream;
     const size_t used = e->a_bytes[si].exchange(0, std::memory_order_relaxed);
     static const size_t in_place_below =
-        getenv("EP_YGO_PACKED_IN_PLACE_BYTES") ? (size_t)atoll(getenv("EP_YGO_PACKED_IN_PLACE_BYTES")) : (size_t)1 << 20;
+        getenv("EP_YGO_PACKED_IN_PLACE_BYTES") ? (size_t)atoll(getenv("EP_YGO_PACKED_IN_PLACE_BYTES")) : (size_t)512 << 10;
     if (e->zero_copy && used <= in_place_below) {
-      // up to about 600 records: the kernel reads the offset table and the records from the pinned slot
+      // up to about 300 records: the kernel reads the offset table and the records from the pinned slot
       // itself - one launch instead of copy + event + wait + launch (33 us of calls), and the bytes
       // start to move with the kernel. Measured through an async pool's recv / send loop: 57 -> 28 us
-      // per batch of 4, 77 -> 42 us per batch of 256, 85 -> 65 us per batch of 512. Larger batches keep
-      // the copy engine's bigger PCIe reads (50 GB/s against 35).
+      // per batch of 4, 58 -> 39 us per batch of 32, 77 -> 42 us per batch of 256. At config 5's 512
+      // records per batch the two ways are within the noise of each other (the workers are the
+      // limit); from there on the copy engine's bigger PCIe reads (50 GB/s against 35) are kept.
       void* dev_tab = nullptr;
       HIP_TRY(hipHostGetDevicePointer(&dev_tab, s.h_tab, 0));
       rc = launch(e, (const char*)dev_tab + e->tab_bytes, B, si, /*lean_fetch=*/true, st, (const uint32_t*)dev_tab);

@@ -30,7 +30,7 @@ def main():
     os.environ["EP_YGO_POOL_SPIN"] = str(spin)
     t0 = _throttle()
     if os.environ.get("ASYNC"):  # config 5's shape (1024 envs, batches of 512) with a free engine
-      r = bench_ygo.run_config5_pool(threads_list=(nt,), batches=400, engine_us=float(os.environ.get("ENGINE_US", "0")))
+      r = bench_ygo.run_config5_pool(threads_list=(nt,), batches=int(os.environ.get("BATCHES", "400")), engine_us=float(os.environ.get("ENGINE_US", "0")))
       v = r["by_threads"][str(nt)]
       print(f"threads {nt:3d}: {v['batches_per_s']:8.0f} batches/s  {v['env_steps_per_s']:.3e} env-steps/s", flush=True)
       continue
