@@ -251,7 +251,7 @@ class EnvPoolFrontEnd:
     info["elapsed_step"] = state["elapsed_step"]
     if reset:
       return state["obs"], info
-    terminated = state["done"] & ~state["trunc"]
+    terminated = state["done"] > state["trunc"]  # done & ~trunc on booleans, in one pass (one kernel for tensors)
     return state["obs"], state["reward"], terminated, state["trunc"], info
 
 
@@ -290,7 +290,7 @@ class GymFrontEnd(EnvPoolFrontEnd):
     if reset:
       return state["obs"], info
     if new_api:
-      return state["obs"], state["reward"], state["done"] & ~state["trunc"], state["trunc"], info
+      return state["obs"], state["reward"], state["done"] > state["trunc"], state["trunc"], info  # (done & ~trunc)
     return state["obs"], state["reward"], state["done"], info
 
 
