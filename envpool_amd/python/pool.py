@@ -195,8 +195,16 @@ class EnvPoolFrontEnd:
     if not hasattr(self, "_recv_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
     descs, _, _ = self._recv_device()
-    from ..interop import as_torch
-    return self._with_mask(self._torch_out(descs, reset), lambda d: as_torch(d, self._torch_dev))
+    return self._with_mask(self._torch_out(descs, reset), self._torch_view)
+
+  def _torch_view(self, desc):
+    """One cached torch view per (address, shape): the ring's slots come round again."""
+    key = (desc[0], tuple(desc[1]))
+    t = self._torch_views.get(key)
+    if t is None:
+      from ..interop import as_torch
+      t = self._torch_views[key] = as_torch(desc, self._torch_dev)
+    return t
 
   def step_torch(self, action, env_id=None):
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
