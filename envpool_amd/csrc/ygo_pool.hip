@@ -15,7 +15,8 @@
 //   worker        -> engine callback -> ep_ygo_emit_record -> row of the batch being filled
 //                    async pools (batch_size < num_envs): rows in ARRIVAL order
 //                    (state_buffer_queue.h:114-128); sync pools: row = position in the sent
-//                    env_id array (`order`, async_envpool.h:69, state_buffer.h:92-95)
+//                    env_id array (`order`, async_envpool.h:69, state_buffer.h:92-95), emitted in
+//                    place, and handed to the encoder in parts of consecutive rows as they complete
 //   recv          -> the next batch in order, encoded (state_buffer_queue.h:139-150)
 //
 // The framework half of Env (env.h:162-222) is here as well: auto-reset of an env one step after
