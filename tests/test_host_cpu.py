@@ -385,3 +385,19 @@ def test_sharded_front_end_async_batches(P):
       pe_g = pe_w = ids
     sh._send(dummy_action(ids, players_env_id=pe_g)); one._send(dummy_action(ids, players_env_id=pe_w))
   assert got == want
+
+
+def test_headers_are_plain_c_and_cxx(tmp_path):
+  """include/*.h is the boundary: it must compile as C99 and as C++11, pedantic, with no warnings,
+  and with nothing but the standard headers."""
+  import shutil
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  src = tmp_path / "hdr.c"
+  src.write_text('#include "envpool_amd.h"\n#include "envpool_amd_ygo.h"\nint main(void) { return 0; }\n')
+  for cc, std, extra in (("gcc", "-std=c99", []), ("g++", "-std=c++11", ["-x", "c++"])):
+    if not shutil.which(cc):
+      continue
+    r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include")] + extra +
+                       ["-c", str(src), "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
