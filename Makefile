@@ -44,7 +44,9 @@ tools/libygosynth.so: tools/ygo_synth.c include/envpool_amd_ygo.h include/envpoo
 
 # Diagnostic programs (launch floors, host-side latencies of the step loop). Not part of `all`.
 # the C ABI from plain C: gcc only, no HIP headers
-examples: examples/dummy_step_loop
+examples: examples/dummy_step_loop examples/ygo_pool_loop
+examples/ygo_pool_loop: examples/ygo_pool_loop.c include/envpool_amd.h include/envpool_amd_ygo.h $(LIB)
+	gcc -O2 -std=c11 -Wall -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
 examples/dummy_step_loop: examples/dummy_step_loop.c include/envpool_amd.h $(LIB)
 	gcc -O2 -std=c11 -Wall -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
 
@@ -79,7 +81,7 @@ build/sanitize_host: tools/sanitize_host.cpp tools/ygo_synth.c $(HIP_SRCS) $(HIP
 	  $(patsubst $(CSRC)/%.hip,build/san_%.o,$(HIP_SRCS)) build/ygo_synth_san.o -pthread
 
 clean:
-	rm -f $(LIB) $(PYMODS) tools/libygosynth.so examples/dummy_step_loop tools/launch_floor tools/host_latency
+	rm -f $(LIB) $(PYMODS) tools/libygosynth.so examples/dummy_step_loop examples/ygo_pool_loop tools/launch_floor tools/host_latency
 	rm -rf build
 	$(MAKE) -C oracle clean
 
