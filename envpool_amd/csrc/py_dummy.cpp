@@ -91,10 +91,14 @@ struct DummyPool {
     }
     epy::check(rc);
   }
-  ~DummyPool() {
+  ~DummyPool() { close(); }
+  // Additive (gym's convention; the reference's pool has no close()): releases the device memory
+  // now instead of when the object dies. Every later call is refused (null pool -> ValueError).
+  void close() {
     if (pool) {
       py::gil_scoped_release rel;
       ep_pool_destroy(pool);
+      pool = nullptr;
     }
   }
   DummyPool(const DummyPool&) = delete;
@@ -322,6 +326,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_sync", &DummyPool::sync)
       .def("_set_recv_timeout", &DummyPool::set_recv_timeout)
       .def("_stream", &DummyPool::stream)
-      .def("_handle", &DummyPool::handle);
+      .def("_handle", &DummyPool::handle)
+      .def("close", &DummyPool::close);
   m.def("device_count", []() { return ep_device_count(); });
 }

@@ -142,3 +142,14 @@ def test_step_torch_front_end(n):
   obs, rew, term, trunc, info = env.step_torch({"list_action": la[:3]}, env_id=sel)
   o._send(dummy_action(np.array([7, 3, 200], np.int32))); w = o._recv()
   assert info["env_id"].cpu().numpy().tolist() == [7, 3, 200] and obs["raw"].cpu().numpy().tobytes() == w[8].tobytes()
+
+
+def test_close_releases_the_pool():
+  """Additive close() (gym's convention): the device memory goes at once, later calls are refused."""
+  import envpool_amd
+  env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=16, seed=1)
+  env.reset()
+  env.close()
+  env.close()   # idempotent
+  with pytest.raises(ValueError):
+    env.reset()
