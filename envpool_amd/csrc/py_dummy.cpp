@@ -2,6 +2,7 @@
 // `_DummyEnvPool` classes of envpool2/dummy/dummy_envpool.cpp:25-31 (REGISTER macro,
 // envpool2/core/py_envpool.h:268-287), implemented over the C ABI in
 // include/envpool_amd.h. No HIP here: this file is host glue only.
+#include <cstdlib>
 #include <cstring>
 
 #include "py_common.h"
@@ -76,8 +77,16 @@ struct DummySpec {
   }
 };
 
-// Above this many envs obs:dyn is handed out lazily (it is O(N^2) bytes).
-constexpr int kEagerDynMaxEnvId = 1024;
+// Above this many envs obs:dyn is handed out lazily (it is O(N^2) bytes: building the
+// exact object array costs 8 us per step at 64 envs, 127 us at 256 and 2 ms at 1024, against 20-30 us
+// for everything else a step does). EP_DUMMY_EAGER_DYN_MAX moves the limit.
+inline int eager_dyn_max_env_id() {
+  static const int v = [] {
+    const char* e = std::getenv("EP_DUMMY_EAGER_DYN_MAX");
+    return e ? std::atoi(e) : 64;
+  }();
+  return v;
+}
 
 struct DummyPool {
   DummySpec spec;
@@ -138,7 +147,7 @@ struct DummyPool {
     const int S = spec.cfg.state_num;
     const auto n = players_env_id.shape(0);
     const int32_t* ids = static_cast<const int32_t*>(players_env_id.data());
-    if (spec.cfg.env_id_offset + spec.cfg.num_envs <= kEagerDynMaxEnvId) {
+    if (spec.cfg.env_id_offset + spec.cfg.num_envs <= eager_dyn_max_env_id()) {
       // exact object array of arrays (py_envpool.h:50-77); row r = full((id+1, S), id)
       // (dummy_envpool.h:154-162, 205-208)
       py::array out(py::dtype("object"), std::vector<py::ssize_t>{n});
