@@ -78,12 +78,12 @@ struct DummySpec {
 };
 
 // Above this many envs obs:dyn is handed out lazily (it is O(N^2) bytes: building the
-// exact object array costs 8 us per step at 64 envs, 127 us at 256 and 2 ms at 1024, against 20-30 us
+// exact object array costs 4 us per step at 32 envs, 12 us at 64, 127 us at 256 and 2 ms at 1024, against 20-30 us
 // for everything else a step does). EP_DUMMY_EAGER_DYN_MAX moves the limit.
 inline int eager_dyn_max_env_id() {
   static const int v = [] {
     const char* e = std::getenv("EP_DUMMY_EAGER_DYN_MAX");
-    return e ? std::atoi(e) : 64;
+    return e ? std::atoi(e) : 32;
   }();
   return v;
 }
