@@ -76,16 +76,36 @@ class ShardedRawPool(metaclass=ABCMeta):
       raise ValueError(f"env_id {bad} is outside this pool [{self._off}, {self._off + self._N})")
     return local // self._n_local
 
+  def _positions(self, env_id: np.ndarray) -> List:
+    """Per shard, where its envs sit in `env_id`: a slice when the ids ascend (the usual case - all
+    envs in order, or any ascending subset: each shard's envs are then one contiguous stretch, found
+    by K + 1 binary searches, and everything downstream works on views), else an index array."""
+    n = env_id.shape[0]
+    if n and (n == 1 or bool((env_id[1:] >= env_id[:-1]).all())):
+      lo, hi = int(env_id[0]) - self._off, int(env_id[-1]) - self._off
+      if lo < 0 or hi >= self._N:
+        raise ValueError(f"env_id {int(env_id[0]) if lo < 0 else int(env_id[-1])} is outside this pool "
+                         f"[{self._off}, {self._off + self._N})")
+      if not hasattr(self, "_edges"):
+        self._edges = (self._off + self._n_local * np.arange(self._K + 1, dtype=np.int64)).astype(np.int64)
+      b = np.searchsorted(env_id, self._edges, side="left")
+      return [slice(int(b[r]), int(b[r + 1])) for r in range(self._K)]
+    owner = self._owner(env_id)
+    return [np.nonzero(owner == r)[0] for r in range(self._K)]
+
+  @staticmethod
+  def _count(p) -> int:
+    return p.stop - p.start if isinstance(p, slice) else int(p.size)
+
   def _fan_out(self, env_id: np.ndarray, per_shard: Callable) -> None:
     env_id = np.ascontiguousarray(env_id, dtype=np.int32)
-    owner = self._owner(env_id)
-    pos = [np.nonzero(owner == r)[0] for r in range(self._K)]
+    pos = self._positions(env_id)
     if self._sync:
       if self._pending:
         raise RuntimeError("a sharded sync pool takes one send (or reset) per recv")
       self._pending.append((env_id.shape[0], pos))
     for r, p in enumerate(pos):
-      if p.size:
+      if self._count(p):
         per_shard(r, p)
 
   def _send(self, action: List[np.ndarray]) -> None:
@@ -94,7 +114,7 @@ class ShardedRawPool(metaclass=ABCMeta):
     rest = [np.asarray(a) for a in action[2:]]
     if self._P == 1:
       def one(r, p):  # single player: action row i belongs to item i (env.h:115-123)
-        self._shards[r]._send([env_id[p].astype(np.int32), penv[p], rest[0][p], rest[1][p], rest[2][p]])
+        self._shards[r]._send([env_id[p].astype(np.int32, copy=False), penv[p], rest[0][p], rest[1][p], rest[2][p]])
     else:
       # players.* arrays have one row per player: a row follows the env its players.env_id names
       # (env.h:128-132); rows that name an env outside the pool match nothing and are dropped
@@ -103,12 +123,12 @@ class ShardedRawPool(metaclass=ABCMeta):
 
       def one(r, p):
         rows = np.nonzero(powner == r)[0]
-        self._shards[r]._send([env_id[p].astype(np.int32), penv[rows], rest[0][p], rest[1][rows], rest[2][rows]])
+        self._shards[r]._send([env_id[p].astype(np.int32, copy=False), penv[rows], rest[0][p], rest[1][rows], rest[2][rows]])
     self._fan_out(env_id, one)
 
   def _reset(self, env_ids: np.ndarray) -> None:
     env_ids = np.asarray(env_ids)
-    self._fan_out(env_ids, lambda r, p: self._shards[r]._reset(env_ids[p].astype(np.int32)))
+    self._fan_out(env_ids, lambda r, p: self._shards[r]._reset(env_ids[p].astype(np.int32, copy=False)))
 
   # ---- stitch ----------------------------------------------------------------------------
   def _recv(self) -> List:
@@ -122,11 +142,27 @@ class ShardedRawPool(metaclass=ABCMeta):
     n, pos = self._pending.popleft()
     if n == 0:
       return self._shards[0]._recv()
+    if all(isinstance(p, slice) for p in pos):
+      # ascending ids: the shards' batches, one after the other, ARE the sent order - one copy per key
+      parts = []
+      for r, p in enumerate(pos):
+        if not self._count(p):
+          continue
+        part = self._shards[r]._recv()
+        if len(part[0]) != self._count(p):
+          raise RuntimeError(f"shard {r} returned {len(part[0])} rows for {self._count(p)} sent envs")
+        parts.append(part)
+      if len(parts) == 1:
+        return parts[0]
+      out = [None if k == _DYN else np.concatenate([q[k] for q in parts]) for k in range(len(parts[0]))]
+      out[_DYN] = _cat_dyn([q[_DYN] for q in parts], out[1], self._S)
+      return out
     out: List = [None] * 12
     dyn_ids = None
     for r, p in enumerate(pos):
-      if not p.size:
+      if not self._count(p):
         continue
+      p = np.arange(p.start, p.stop) if isinstance(p, slice) else p
       part = self._shards[r]._recv()
       if len(part[0]) != p.size:
         raise RuntimeError(f"shard {r} returned {len(part[0])} rows for {p.size} sent envs")
