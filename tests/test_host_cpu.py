@@ -337,6 +337,12 @@ def test_sharded_front_end_stitches_in_sent_order():
       sel = rng.permutation(ids)[: int(rng.integers(1, K * n))]
     elif t % 7 == 5:    # everything that one shard owns, nothing else
       sel = ids[n:2 * n][::-1].copy()
+    elif t % 7 == 0:    # every env in order: the path of slices
+      sel = ids
+    elif t % 7 == 1:    # an ascending subset (some shards may get nothing): slices as well
+      sel = np.sort(rng.permutation(ids)[: int(rng.integers(1, K * n))])
+    elif t % 7 == 2:    # ascending, one shard only
+      sel = ids[2 * n + 5:3 * n - 7]
     else:
       sel = rng.permutation(ids)
     pe = sel + (rng.random(sel.size) < 0.1).astype(np.int32)
