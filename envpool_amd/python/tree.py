@@ -21,9 +21,16 @@ def nest(flat: Dict[str, Any], factory: Callable[[], Any] = dict) -> Any:
   return root
 
 
+_NT_CLASSES: Dict[Tuple, Any] = {}
+
+
 def as_namedtuple(name: str, tree: Dict[str, Any]) -> Tuple:
-  fields = list(tree.keys())
-  cls = namedtuple(name, fields)
+  # (one class per (name, fields), made once: building a namedtuple class costs ~15 us, and the dm
+  # flavour needs four of them per step)
+  key = (name, tuple(tree.keys()))
+  cls = _NT_CLASSES.get(key)
+  if cls is None:
+    cls = _NT_CLASSES[key] = namedtuple(name, list(tree.keys()))
   return cls(*[as_namedtuple(k, v) if isinstance(v, dict) else v for k, v in tree.items()])
 
 
