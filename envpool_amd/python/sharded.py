@@ -91,6 +91,11 @@ class ShardedRawPool(metaclass=ABCMeta):
       b = np.searchsorted(env_id, self._edges, side="left")
       return [slice(int(b[r]), int(b[r + 1])) for r in range(self._K)]
     owner = self._owner(env_id)
+    if n and bool((owner[1:] >= owner[:-1]).all()):
+      # grouped by shard, in any order inside a shard (the env ids of a batch this front-end handed
+      # out: an async actor loop sends back exactly that): slices as well
+      b = np.searchsorted(owner, np.arange(self._K + 1), side="left")
+      return [slice(int(b[r]), int(b[r + 1])) for r in range(self._K)]
     return [np.nonzero(owner == r)[0] for r in range(self._K)]
 
   @staticmethod
