@@ -58,6 +58,7 @@ def lib():
     L.rp_destroy.argtypes = [C.c_void_p]
     L.rp_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.rp_send.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rp_send_copy.argtypes = L.rp_send.argtypes
     L.rp_recv.argtypes = [C.c_void_p, C.POINTER(_Batch)]
     L.rp_batch_free.argtypes = [C.POINTER(_Batch)]
     L.rp_num_threads.argtypes = [C.c_void_p]
@@ -167,8 +168,10 @@ def _unpack(b, free, dyn="lazy"):
 
 class ThreadedDummyOracle:
   """dummy_pool_mt.c: ActionBufferQueue -> worker threads -> StateBufferQueue, as the reference
-  runs it. `_recv` blocks like the reference's. The arrays of a `_send` are kept alive here until
-  the env's next send (envpool2/core/env.h:106-110 holds the batch the same way)."""
+  runs it. `_recv` blocks like the reference's. `_send` hands the pool its own copy of the action
+  arrays, released with the batch's last reference (envpool2/core/env.h:106-110 and
+  py_envpool.h:88-100 hold and release the numpy arrays the same way); keeping them alive on the
+  Python side "for long enough" is what a descheduled worker can outlast."""
 
   def __init__(self, num_envs=1, batch_size=0, max_num_players=1, seed=42,
                max_episode_steps=2**31 - 1, state_num=10, num_threads=0):
@@ -178,7 +181,6 @@ class ThreadedDummyOracle:
     if not self._p:
       raise ValueError("invalid oracle config")
     self.num_envs, self.state_num = num_envs, state_num
-    self._keep = []
 
   def close(self):
     if getattr(self, "_p", None):
@@ -204,10 +206,7 @@ class ThreadedDummyOracle:
     penv = np.ascontiguousarray(action[1], dtype=np.int32)
     la = np.ascontiguousarray(action[2], dtype=np.float64)
     assert la.shape == (env_id.shape[0], 6)
-    self._keep.append((env_id, penv, la))
-    if len(self._keep) > 4 * (self.num_envs + 4):
-      del self._keep[:len(self._keep) // 2]
-    self._L.rp_send(self._p, env_id.shape[0], env_id.ctypes.data, penv.shape[0], penv.ctypes.data,
+    self._L.rp_send_copy(self._p, env_id.shape[0], env_id.ctypes.data, penv.shape[0], penv.ctypes.data,
                     la.ctypes.data)
 
   def _recv(self):

@@ -243,6 +243,10 @@ typedef struct {
   const double* list_action;
   int32_t np_rows;
   _Atomic int32_t refs; /* the shared_ptr<vector<Array>> of async_envpool.h:62-63 */
+  /* py_envpool.h:88-100: the numpy arrays behind the batch are released when the last env drops
+   * it. NULL = the caller keeps the arrays alive itself (rp_send). */
+  void (*release)(void*);
+  void* release_ctx;
 } rp_action_batch;
 
 typedef struct {
@@ -286,7 +290,10 @@ static void buffer_done(rp_pool* p, rp_buffer* b, uint64_t num) { /* state_buffe
 static inline int is_done(const rp_env* e) { return e->state >= e->seed; }
 
 static void batch_unref(rp_action_batch* a) {
-  if (a && atomic_fetch_sub(&a->refs, 1) == 1) free(a);
+  if (a && atomic_fetch_sub(&a->refs, 1) == 1) {
+    if (a->release) a->release(a->release_ctx);
+    free(a);
+  }
 }
 
 /* Env::EnvStep (env.h:162-172) for one slice, run by a worker */
@@ -417,15 +424,23 @@ void rp_destroy(rp_pool* p) {
 }
 
 /* AsyncEnvPool::SendImpl (async_envpool.h:57-80). The action arrays are used in place, as the
- * reference uses the numpy memory: the caller keeps them alive until the rows they produce have
- * been received. An env must not be sent again before its previous step was received (the same
- * contract the reference's SetAction relies on). */
-void rp_send(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
-             const int32_t* players_env_id, const double* list_action) {
+ * reference uses the numpy memory, and like the reference's (py_envpool.h:88-100: incref at Send,
+ * decref from the deleter of the shared batch) their lifetime is the batch's: `release(ctx)` runs
+ * when the last env that was sent with them has been sent again (env.h:106-110) or the pool is
+ * destroyed. A worker that has dequeued a slice but not yet read its action row holds no reference
+ * of its own — the env's `batch` pointer does — so nothing but that count says when the arrays may
+ * go: a caller that recycles them on any other schedule (a fixed rotation, "after the rows were
+ * received") races with such a worker. An env must not be sent again before its previous step
+ * was received (the same contract the reference's SetAction relies on). */
+static void send_impl(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
+                      const int32_t* players_env_id, const double* list_action,
+                      void (*release)(void*), void* ctx) {
   rp_action_batch* a = calloc(1, sizeof(*a));
   a->players_env_id = players_env_id;
   a->list_action = list_action;
   a->np_rows = np_rows;
+  a->release = release;
+  a->release_ctx = ctx;
   atomic_store(&a->refs, n + 1);
   rp_slice* actions = malloc((size_t)(n > 0 ? n : 1) * sizeof(rp_slice));
   for (int i = 0; i < n; ++i) {
@@ -439,6 +454,33 @@ void rp_send(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
   abq_enqueue_bulk(&p->abq, actions, (size_t)n);
   free(actions);
   batch_unref(a);
+}
+
+/* The caller keeps `players_env_id` / `list_action` alive for as long as the pool lives (the bench
+ * leg: one set of arrays for the whole run). */
+void rp_send(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
+             const int32_t* players_env_id, const double* list_action) {
+  send_impl(p, n, env_id, np_rows, players_env_id, list_action, NULL, NULL);
+}
+
+/* The pool releases the arrays: `release(ctx)` is called exactly once, from whichever thread drops
+ * the batch's last reference. */
+void rp_send_owned(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
+                   const int32_t* players_env_id, const double* list_action,
+                   void (*release)(void*), void* ctx) {
+  send_impl(p, n, env_id, np_rows, players_env_id, list_action, release, ctx);
+}
+
+/* The pool works on its own copy of the arrays (one heap block, freed with the batch): what a
+ * binding without reference counting — ctypes — uses. */
+void rp_send_copy(rp_pool* p, int32_t n, const int32_t* env_id, int32_t np_rows,
+                  const int32_t* players_env_id, const double* list_action) {
+  size_t la_bytes = (size_t)(n > 0 ? n : 0) * 6 * sizeof(double);
+  size_t pe_bytes = (size_t)(np_rows > 0 ? np_rows : 0) * sizeof(int32_t);
+  char* blk = malloc(la_bytes + pe_bytes + 8);
+  memcpy(blk, list_action, la_bytes);
+  memcpy(blk + la_bytes, players_env_id, pe_bytes);
+  send_impl(p, n, env_id, np_rows, (const int32_t*)(blk + la_bytes), (const double*)blk, free, blk);
 }
 
 void rp_reset(rp_pool* p, const int32_t* env_ids, int32_t n) { /* async_envpool.h:176-189 */

@@ -15,11 +15,14 @@ typedef struct {
 } rp_batch;
 rp_pool* rp_create(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t);
 void rp_destroy(rp_pool*);
-void rp_send(rp_pool*, int32_t, const int32_t*, int32_t, const int32_t*, const double*);
+void rp_send_owned(rp_pool*, int32_t, const int32_t*, int32_t, const int32_t*, const double*,
+                   void (*)(void*), void*);
 void rp_reset(rp_pool*, const int32_t*, int32_t);
 void rp_recv(rp_pool*, rp_batch*);
 void rp_batch_free(rp_batch*);
 uint64_t rp_bench_sync(int32_t, int32_t, int32_t, int32_t);
+
+typedef struct { int32_t ids[64]; double la[6 * 64]; } sent_set;
 
 int main(void) {
   /* sync: 2000 envs, 4 workers, 30 lockstep steps */
@@ -30,27 +33,28 @@ int main(void) {
   int32_t* ids = malloc(sizeof(int32_t) * N);
   for (int i = 0; i < N; ++i) ids[i] = i;
   rp_reset(p, ids, N);
-  /* action arrays must outlive the step they feed: one set per batch in flight */
-  enum { SETS = 16 };
-  int32_t* sent_ids[SETS];
-  double* sent_la[SETS];
-  for (int k = 0; k < SETS; ++k) { sent_ids[k] = malloc(sizeof(int32_t) * B); sent_la[k] = malloc(sizeof(double) * 6 * B); }
+  /* Action arrays live as long as the batch they were sent as: a worker that has dequeued an env
+   * but not yet read its action row is only protected by the batch's reference count
+   * (dummy_pool_mt.c:send_impl), not by anything the receiver can observe — a fixed rotation of
+   * array sets ("one per batch in flight") was lapped by the other 255 envs while one worker was
+   * descheduled, which ThreadSanitizer reported in round 2. So: one heap block per send, released
+   * by the pool from the last unref, as the reference releases its numpy arrays
+   * (py_envpool.h:88-100). */
   for (int it = 0; it < 200; ++it) {
     rp_batch b;
     rp_recv(p, &b);
     if (b.num_rows != B) { fprintf(stderr, "batch of %d rows\n", b.num_rows); return 2; }
-    const int k = it % SETS;
+    sent_set* s = malloc(sizeof(sent_set));
     for (int j = 0; j < B; ++j) {
-      sent_ids[k][j] = b.info_env_id[j];
-      for (int q = 0; q < 6; ++q) sent_la[k][6 * j + q] = 1.5;
+      s->ids[j] = b.info_env_id[j];
+      for (int q = 0; q < 6; ++q) s->la[6 * j + q] = 1.5;
       sum += (uint64_t)b.elapsed_step[j];
     }
     rp_batch_free(&b);
-    rp_send(p, B, sent_ids[k], B, sent_ids[k], sent_la[k]);
+    rp_send_owned(p, B, s->ids, B, s->ids, s->la, free, s);
   }
   for (int it = 0; it < N / B; ++it) { rp_batch b; rp_recv(p, &b); rp_batch_free(&b); }
   rp_destroy(p);
-  for (int k = 0; k < SETS; ++k) { free(sent_ids[k]); free(sent_la[k]); }
   free(ids);
   printf("tsan_driver: done, checksum %llu; no ThreadSanitizer report\n", (unsigned long long)sum);
   return 0;
