@@ -43,6 +43,7 @@ SYMBOLS = [
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
   "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
   "ep_last_error", "ep_version", "ep_dummy_send_noalloc", "ep_pool_step", "ep_pool_last_rollout_kernel",
+  "ep_pool_step_begin", "ep_pool_step_end", "ep_pool_server_stats", "ep_pool_server_trace",
 ]
 
 _bound = None
@@ -62,6 +63,9 @@ def lib():
     L.ep_pool_recv_on_stream.argtypes = [vp, vp, C.POINTER(Batch)]
     L.ep_pool_set_recv_timeout.argtypes = [vp, i64]
     L.ep_pool_step.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(Batch)]
+    L.ep_pool_step_begin.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.ep_pool_step_end.argtypes = [vp, C.POINTER(Batch)]
+    L.ep_pool_server_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.ep_pool_last_rollout_kernel.argtypes = [vp]
     L.ep_pool_last_rollout_kernel.restype = C.c_char_p
     L.ep_pool_episode_stats_async.argtypes = [vp, vp, vp, vp, vp]
@@ -232,6 +236,12 @@ class DummyPoolC:
 
   def sync(self):
     _check(self._L.ep_pool_sync(self._h))
+
+  def server_stats(self):
+    """(kernels launched, idle stops, steps served, idle limit in us) of the resident step server."""
+    a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int64()
+    _check(self._L.ep_pool_server_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
 
   def episode_stats(self):
     n = self._L.ep_pool_num_envs(self._h)

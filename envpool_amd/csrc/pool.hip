@@ -13,6 +13,11 @@
 //   semaphores / StateBuffer::Wait (state_buffer.h:135-157) -> one hipEvent per slot.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#if defined(__linux__)
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -29,6 +34,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dummy_kernels.hpp"
@@ -130,9 +136,30 @@ struct ep_pool {
   epk::ServerCtl* h_ctl = nullptr;  // host-mapped doorbell / answer lines
   epk::ServerCtl* d_ctl = nullptr;
   unsigned long long* d_server_words = nullptr;  // device flag line + fan-in counter lines
+  unsigned long long* bar_bell = nullptr;  // fine-grained DEVICE word the host writes through the PCIe BAR: the doorbell every
+                                           // workgroup polls (null: no large BAR, or EP_SERVER_BAR=0: round 2's leader wake-up)
   bool server_running = false;
   uint32_t server_seq = 0;
   const void* server_arrays[3]{};
+  bool spin_pause = false;  // EP_SERVER_PAUSE=1: a PAUSE in the host's wait loop (round 2 had one)
+  bool server_two_level = false;  // EP_SERVER_JOIN=2: round 2's two-level join (one host word)
+  int server_shards = 0;       // shard words the host waits for (min(workgroups, kServerShards))
+  int step_mode = 0;           // ep_pool_step_begin .. ep_pool_step_end: 0 none, 1 the server has been rung, 2 send + recv
+  bool step_warm = false;      // the step in flight found the server running (it was not started for it)
+  uint64_t step_bi = 0;
+  // idle watchdog: stops the server when no step has come for idle_limit_us (about 10 x the last
+  // gap between two steps, 200 us .. 50 ms), so that a device-wide synchronisation of the caller,
+  // which has to wait for the resident kernel to end, is held up for that long at most
+  std::thread wd;
+  std::condition_variable wd_cv;
+  bool wd_started = false, wd_quit = false;
+  std::chrono::steady_clock::time_point last_ring{};
+  int64_t idle_limit_us = 200;
+  uint32_t idle_streak = 0;     // idle stops in a row with no warm step between them
+  uint32_t server_backoff = 0;  // steps that take the launch path before the server is tried again
+  uint64_t server_launches = 0, server_idle_stops = 0, server_steps = 0;
+  unsigned long long* d_server_trace = nullptr;  // EP_SERVER_TRACE=1: per workgroup 4 timestamps of its last step
+  int server_wgs = 0;
   int cu_count = 0;
   bool use_server = true;  // EP_STEP_SERVER=0: ep_pool_step always takes the launch-per-step path
   bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
@@ -393,13 +420,49 @@ uint32_t next_stamp(ep_pool* p) {  // stamp of the launch about to be enqueued: 
 // Asks a running server to leave and waits until its kernel has ended. Every entry point that
 // enqueues work on the pool's streams or reads the env state calls this first: while the server
 // runs, it alone owns the env records and the ring.
+void ring_bell(ep_pool* p, unsigned long long v) {
+  if (p->bar_bell) {
+    // device memory through the BAR: a write-combining mapping, so the store is pushed out at once
+    *(volatile unsigned long long*)p->bar_bell = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (host-only function: nothing to emit in the device pass)
+#elif defined(__x86_64__)
+    _mm_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+  } else {
+    __atomic_store_n(&p->h_ctl->bell, v, __ATOMIC_RELEASE);
+  }
+}
+
 int server_stop(ep_pool* p) {
+  if (p->step_mode == 1)
+    return fail(EP_ERR_INVALID, "a step is in flight (ep_pool_step_begin): call ep_pool_step_end first");
   if (!p->server_running) return EP_OK;
-  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq | epk::kServerQuit, __ATOMIC_RELEASE);
+  ring_bell(p, (unsigned long long)p->server_seq | epk::kServerQuit);
   HIP_TRY(hipStreamSynchronize(p->server_stream));  // (the kernel leaves within a poll of seeing the flag, or has left already)
-  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq, __ATOMIC_RELEASE);
+  ring_bell(p, (unsigned long long)p->server_seq);
   p->server_running = false;
   return EP_OK;
+}
+
+// The idle watchdog (one thread per pool, started with the first server): see ep_pool::wd.
+void server_watchdog(ep_pool* p) {
+  std::unique_lock<std::mutex> lk(p->mu);
+  while (!p->wd_quit) {
+    if (!p->server_running) { p->wd_cv.wait(lk); continue; }
+    const auto limit = std::chrono::microseconds(p->idle_limit_us);
+    if (p->step_mode == 1) { p->wd_cv.wait_for(lk, limit); continue; }
+    const auto deadline = p->last_ring + limit;
+    if (std::chrono::steady_clock::now() < deadline) { p->wd_cv.wait_until(lk, deadline); continue; }
+    if (hipSetDevice(p->device) != hipSuccess || server_stop(p) != EP_OK) { p->wd_cv.wait_for(lk, std::chrono::milliseconds(50)); continue; }
+    ++p->server_idle_stops;
+    // a caller that keeps letting the server run idle (one that synchronises the device after every
+    // step, or steps rarely) is served by the launch path for a while: 8, 16, ... 1024 steps
+    p->idle_streak = std::min(p->idle_streak + 1, 8u);
+    p->server_backoff = 4u << p->idle_streak;
+  }
 }
 
 // Starts the server for the action arrays `arrs` (env_id, players.env_id, list_action on the
@@ -411,10 +474,11 @@ int server_start(ep_pool* p, const void* const* arrs) {
   if (int rc = sync_stream_unlocked(p, nullptr)) return rc;
   HIP_TRY(hipMemsetAsync(p->d_server_words, 0, 128 * (2 + epk::kServerShards), p->server_stream));
   p->h_ctl->alive = 1;
-  __atomic_store_n(&p->h_ctl->done, p->server_seq, __ATOMIC_RELEASE);
-  __atomic_store_n(&p->h_ctl->bell, (unsigned long long)p->server_seq, __ATOMIC_RELEASE);
+  for (int s = 0; s < epk::kServerShards; ++s) __atomic_store_n(&p->h_ctl->done[s], p->server_seq, __ATOMIC_RELEASE);
+  ring_bell(p, (unsigned long long)p->server_seq);
   epk::ServerArgs a;
   a.ctl = p->d_ctl;
+  a.bell_dev = p->bar_bell;
   a.dev_flag = p->d_server_words;
   a.counters = reinterpret_cast<uint32_t*>(p->d_server_words + 16);  // the line after the flag's
   a.env_id = (const int32_t*)arrs[0];
@@ -432,15 +496,29 @@ int server_start(ep_pool* p, const void* const* arrs) {
   a.pc = pool_const(p);
   a.first_step = p->server_seq + 1;
   a.bi0 = p->alloc_count / (uint64_t)p->B;
-  a.idle_polls = 40000;  // about 50 ms of doorbell polls
+  // the kernel's own limit is a last resort (the host stops the server: every other entry point,
+  // the idle watchdog, ep_pool_destroy): about a second of polls
+  a.idle_polls = p->bar_bell ? 1500000u : 800000u;
   a.num_tiles = p->N / epk::kBlock;
   const int n_wg = std::min(a.num_tiles, std::max(1, p->cu_count));
   a.tiles_per_wg = (a.num_tiles + n_wg - 1) / n_wg;
+  a.trace = p->d_server_trace;
+  a.two_level_join = p->server_two_level ? 1 : 0;
+  p->server_wgs = n_wg;
   if (p->S == 10) hipLaunchKernelGGL(epk::dummy_step_server<10>, dim3(n_wg), dim3(epk::kBlock), 0, p->server_stream, a);
   else hipLaunchKernelGGL(epk::dummy_step_server<0>, dim3(n_wg), dim3(epk::kBlock), 0, p->server_stream, a);
   HIP_TRY(hipGetLastError());
   p->server_running = true;
+  p->server_shards = p->server_two_level ? 1 : std::min(n_wg, epk::kServerShards);
+  ++p->server_launches;
+  p->last_ring = std::chrono::steady_clock::now();
   for (int k = 0; k < 3; ++k) p->server_arrays[k] = arrs[k];
+  if (!p->wd_started) {
+    p->wd_started = true;
+    p->wd = std::thread(server_watchdog, p);
+  } else {
+    p->wd_cv.notify_one();
+  }
   return EP_OK;
 }
 
@@ -791,6 +869,35 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   HIP_TRY(hipMalloc((void**)&p->d_server_words, 128 * (2 + epk::kServerShards)));
   HIP_TRY(hipDeviceGetAttribute(&p->cu_count, hipDeviceAttributeMultiprocessorCount, p->device));
   if (const char* sv = getenv("EP_STEP_SERVER")) p->use_server = sv[0] != '0';
+  {
+    // the server's doorbell: a word of fine-grained device memory the host can write (large BAR)
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) != hipSuccess) large_bar = 0;
+    if (const char* tr = getenv("EP_SERVER_TRACE"))
+      if (tr[0] == '1') {
+        HIP_TRY(hipMalloc((void**)&p->d_server_trace, 8 * 4 * 1024));
+        HIP_TRY(hipMemset(p->d_server_trace, 0, 8 * 4 * 1024));
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+        // where the host side of the doorbell round trip lives: the CPU this thread runs on and the
+        // NUMA node of the host-mapped answer line (a GPU write into the far socket's memory is slower)
+        void* page = (void*)((uintptr_t)p->h_ctl & ~(uintptr_t)4095);
+        int node = -1;
+        (void)syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &node, 0);
+        fprintf(stderr, "[ep trace] pool %p: cpu %d, answer line on NUMA node %d\n", (void*)p.get(), sched_getcpu(), node);
+#endif
+      }
+    if (const char* sj = getenv("EP_SERVER_JOIN")) p->server_two_level = sj[0] == '2';
+    if (const char* sp = getenv("EP_SERVER_PAUSE")) p->spin_pause = sp[0] == '1';
+    const char* sb = getenv("EP_SERVER_BAR");
+    if (large_bar && !(sb && sb[0] == '0')) {
+      if (hipExtMallocWithFlags((void**)&p->bar_bell, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+        HIP_TRY(hipMemset(p->bar_bell, 0, 4096));
+      } else {
+        (void)hipGetLastError();
+        p->bar_bell = nullptr;
+      }
+    }
+  }
   p->slots.resize(p->Q);
   HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
@@ -807,7 +914,15 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
 int ep_pool_destroy(ep_pool* p) {
   if (!p) return EP_OK;
   (void)hipSetDevice(p->device);
+  if (p->wd_started) {
+    { std::lock_guard<std::mutex> lk(p->mu); p->wd_quit = true; }
+    p->wd_cv.notify_all();
+    p->wd.join();
+  }
+  p->step_mode = 0;
   (void)server_stop(p);
+  (void)hipFree(p->bar_bell);
+  (void)hipFree(p->d_server_trace);
   (void)hipStreamSynchronize(p->stream);
   (void)hipStreamSynchronize(p->copy_stream);
   if (p->server_stream) (void)hipStreamDestroy(p->server_stream);
@@ -1284,50 +1399,109 @@ int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   return status;
 }
 
-int ep_pool_step(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims, ep_batch* out) {
-  if (!p || !arrays || !leading_dims || !out) return fail(EP_ERR_INVALID, "null argument");
+int ep_pool_step_begin(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims) {
+  if (!p || !arrays || !leading_dims) return fail(EP_ERR_INVALID, "null argument");
   if (n_arrays != 5) return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays in _action_keys order, got %d", n_arrays);
   {
     std::unique_lock<std::mutex> lk(p->mu);
     int rc = set_device(p);
     if (rc) return rc;
+    if (p->step_mode != 0) return fail(EP_ERR_INVALID, "the previous ep_pool_step_begin has not been ended");
     const bool whole = leading_dims[0] == p->N && leading_dims[1] == p->N && leading_dims[2] == p->N;
     const bool aligned = arrays[0] && arrays[1] && arrays[2] && !((uintptr_t)arrays[0] & 3) && !((uintptr_t)arrays[1] & 3) &&
                          !((uintptr_t)arrays[2] & 15);
     const bool idle = p->alloc_count == p->done_ptr * (uint64_t)p->B && p->stepping_env_num == 0;
-    if (p->use_server && !p->force_generic && p->is_sync && whole && aligned && idle && p->N % epk::kBlock == 0 && !p->poisoned) {
+    bool serve = p->use_server && !p->force_generic && p->is_sync && whole && aligned && idle && p->N % epk::kBlock == 0 && !p->poisoned;
+    if (serve && !p->server_running && p->server_backoff > 0) {
+      --p->server_backoff;  // the server ran idle lately (server_watchdog): the launch path for now
+      serve = false;
+    }
+    if (serve) {
       // ---- the resident server: no launch ---------------------------------------------
+      if (p->server_running && __atomic_load_n(&p->h_ctl->alive, __ATOMIC_ACQUIRE) == 0) {
+        // its own poll limit ran out (the watchdog should have stopped it long before): wait for the kernel to end
+        HIP_TRY(hipStreamSynchronize(p->server_stream));
+        p->server_running = false;
+      }
       if (p->server_running && (p->server_arrays[0] != arrays[0] || p->server_arrays[1] != arrays[1] || p->server_arrays[2] != arrays[2]))
         if ((rc = server_stop(p))) return rc;  // other action arrays: the server is started again for them
       const uint64_t bi = p->alloc_count / (uint64_t)p->B;
       if ((rc = claim_err_word(p, bi))) return rc;
-      if (!p->server_running && (rc = server_start(p, arrays))) return rc;
-      const uint32_t seq = ++p->server_seq;
-      __atomic_store_n(&p->h_ctl->bell, (unsigned long long)seq, __ATOMIC_RELEASE);
+      const bool warm = p->server_running;
+      if (!warm && (rc = server_start(p, arrays))) return rc;
+      const auto now = std::chrono::steady_clock::now();
+      if (warm) {
+        // the server's patience follows the caller's cadence: about ten gaps, 200 us .. 50 ms
+        const int64_t gap = std::chrono::duration_cast<std::chrono::microseconds>(now - p->last_ring).count();
+        p->idle_limit_us = std::min<int64_t>(50000, std::max<int64_t>(200, 10 * gap));
+      }
+      p->last_ring = now;
+      p->step_warm = warm;
+      p->step_bi = bi;
+      ring_bell(p, (unsigned long long)++p->server_seq);
+      p->step_mode = 1;
+      return EP_OK;
+    }
+  }
+  // ---- anything else: one launch per step (send now, blocking recv in ep_pool_step_end) -----------
+  int rc = ep_pool_send(p, n_arrays, arrays, leading_dims, EP_MEM_DEVICE);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(p->mu);
+  p->step_mode = 2;
+  return EP_OK;
+}
+
+int ep_pool_step_end(ep_pool* p, ep_batch* out) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    int rc = set_device(p);
+    if (rc) return rc;
+    if (p->step_mode == 0) return fail(EP_ERR_INVALID, "ep_pool_step_end without ep_pool_step_begin");
+    if (p->step_mode == 1) {
+      const uint32_t seq = p->server_seq;
+      const int ns = p->server_shards;
+      auto all_done = [&]() {
+        for (int s = 0; s < ns; ++s)
+          if (__atomic_load_n(&p->h_ctl->done[s], __ATOMIC_ACQUIRE) != seq) return false;
+        return true;
+      };
       const auto t0 = std::chrono::steady_clock::now();
       for (uint32_t spins = 0;; ++spins) {
-        if (__atomic_load_n(&p->h_ctl->done, __ATOMIC_ACQUIRE) == seq) break;
+        if (all_done()) break;
         if ((spins & 1023u) == 1023u) {
           if (__atomic_load_n(&p->h_ctl->alive, __ATOMIC_ACQUIRE) == 0) {
-            // the server left (its idle limit ran out as the doorbell rang): wait for its kernel to
-            // end; unless it answered on its way out, start a new one for this very step
+            // the kernel's own poll limit ran out as the doorbell rang: wait for the kernel to end
             HIP_TRY(hipStreamSynchronize(p->server_stream));
             p->server_running = false;
-            if (__atomic_load_n(&p->h_ctl->done, __ATOMIC_ACQUIRE) == seq) break;
+            if (all_done()) break;
+            if (p->bar_bell) {
+              // (each workgroup decides for itself there: some may have served the step, some not)
+              p->step_mode = 0;
+              p->poisoned = true;
+              return fail(EP_ERR_HIP, "the step server gave up waiting while a step was rung: the pool's state is undefined");
+            }
+            // leader wake-up: the leader decides for all, so the step was not served at all: a new server for this very step
             --p->server_seq;
-            if ((rc = server_start(p, arrays))) return rc;
-            ++p->server_seq;
-            __atomic_store_n(&p->h_ctl->bell, (unsigned long long)seq, __ATOMIC_RELEASE);
+            p->step_mode = 0;
+            if ((rc = server_start(p, p->server_arrays))) return rc;
+            p->step_mode = 1;
+            ring_bell(p, (unsigned long long)++p->server_seq);
           }
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            p->step_mode = 0;
             p->poisoned = true;
             return fail(EP_ERR_HIP, "the step server did not answer within 5 s");
           }
         }
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+        if (p->spin_pause) __builtin_ia32_pause();
 #endif
       }
+      p->step_mode = 0;
+      ++p->server_steps;
+      if (p->step_warm) p->idle_streak = 0;
+      const uint64_t bi = p->step_bi;
       const int slot = (int)(bi % (uint64_t)p->Q);
       const int status = status_of_err_bits(take_err_bits(p, err_index(p, bi)), "step");
       p->alloc_count += (uint64_t)p->B;  // one whole batch allocated ...
@@ -1351,11 +1525,38 @@ int ep_pool_step(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
       }
       return status;
     }
+    p->step_mode = 0;
   }
-  // ---- anything else: one launch per step (send + blocking recv) ------------------------------
-  int rc = ep_pool_send(p, n_arrays, arrays, leading_dims, EP_MEM_DEVICE);
-  if (rc) return rc;
   return ep_pool_recv(p, EP_MEM_DEVICE, out);
+}
+
+int ep_pool_step(ep_pool* p, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims, ep_batch* out) {
+  if (!out) return fail(EP_ERR_INVALID, "null argument");
+  int rc = ep_pool_step_begin(p, n_arrays, arrays, leading_dims);
+  if (rc) return rc;
+  return ep_pool_step_end(p, out);
+}
+
+int ep_pool_server_trace(ep_pool* p, uint64_t* out, int32_t max_workgroups) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if (!p->d_server_trace) return fail(EP_ERR_INVALID, "no trace: create the pool with EP_SERVER_TRACE=1 in the environment");
+  if ((rc = server_stop(p))) return rc;
+  const int n = std::min(std::min(max_workgroups, p->server_wgs), 1024);
+  if (n > 0) HIP_TRY(hipMemcpy(out, p->d_server_trace, 32 * (size_t)n, hipMemcpyDeviceToHost));
+  return n < 0 ? 0 : -n;  // (negative count: the number of workgroups written; 0 = none)
+}
+
+int ep_pool_server_stats(ep_pool* p, uint64_t* launches, uint64_t* idle_stops, uint64_t* steps_served, int64_t* idle_limit_us) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (launches) *launches = p->server_launches;
+  if (idle_stops) *idle_stops = p->server_idle_stops;
+  if (steps_served) *steps_served = p->server_steps;
+  if (idle_limit_us) *idle_limit_us = p->idle_limit_us;
+  return EP_OK;
 }
 
 int ep_pool_set_recv_timeout(ep_pool* p, int64_t milliseconds) {
@@ -1537,6 +1738,11 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
                   k, (long long)out[k].shape[0], (long long)need);
     if ((uintptr_t)out[k].data & (sk == 8 ? 15 : (size_t)kSlotElem[sk] - 1))
       return fail(EP_ERR_INVALID, "output array %d is misaligned (obs:raw needs 16 bytes)", k);
+    // the kernels write state_num int32 per obs:raw row (as 16- and 8-byte stores): an array laid
+    // out for another state_num would be overrun without a word
+    if (sk == 8 ? (out[k].ndim != 2 || out[k].shape[1] != S) : out[k].ndim != 1)
+      return fail(EP_ERR_INVALID, sk == 8 ? "output array %d (obs:raw) must have shape [rows, state_num = %d]"
+                                          : "output array %d must be one-dimensional", k, S);
   }
   if (cfg->device_id < 0 || cfg->device_id >= kNoallocMaxDevices) return fail(EP_ERR_INVALID, "device_id %d out of range", cfg->device_id);
   HIP_TRY(hipSetDevice(cfg->device_id));
@@ -1565,11 +1771,16 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   ms.tiles = (unsigned long long*)(sc + kNoallocTilesOff);
   ms.counts = (unsigned long long*)(sc + kNoallocCountsOff);
   const uint32_t epoch = 1;  // the words were just cleared: no tag from an earlier call can match
-  if (P > 1 && !force_reset && np_rows > 0) {
+  if (P > 1 && !force_reset) {
+    // every call uses epoch 1, so the previous call's counters carry a matching tag: they are
+    // cleared on every multi-player step, also one that brings no player rows at all (its envs
+    // must see action_num = 0, not the last call's histogram)
     HIP_TRY(hipMemsetAsync(ms.counts, 0, 8 * (size_t)N, st));
-    hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, st, players_env_id, np_rows,
-                       cfg->env_id_offset, N, ms.counts, epoch);
-    HIP_TRY(hipGetLastError());
+    if (np_rows > 0) {
+      hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, st, players_env_id, np_rows,
+                         cfg->env_id_offset, N, ms.counts, epoch);
+      HIP_TRY(hipGetLastError());
+    }
   }
   epk::MpFusedArgs a;
   a.env_id = env_id;

@@ -258,6 +258,39 @@ struct DummyPool {
     return py::make_tuple(out, b.num_rows, b.num_player_rows);
   }
 
+  // ep_pool_step in two halves (ep_pool_step_begin / ep_pool_step_end): a front-end over several
+  // pools rings every pool first and then waits for each.
+  void step_begin(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims) {
+    if (ptrs.size() != 5 || dims.size() != 5) throw std::invalid_argument("need 5 pointers and 5 dims");
+    const void* p[5];
+    for (int i = 0; i < 5; ++i) p[i] = reinterpret_cast<const void*>(ptrs[i]);
+    epy::check(ep_pool_step_begin(pool, 5, p, dims.data()));
+  }
+  py::tuple step_end() {
+    ep_batch b;
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_step_end(pool, &b);
+    }
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    std::string deferred = batch_with_error ? ep_last_error() : "";
+    py::list out;
+    for (int k = 0; k < b.num_keys; ++k) {
+      if (b.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
+      else out.append(epy::device_desc(b.arrays[k]));
+    }
+    if (!deferred.empty()) throw std::runtime_error(deferred);
+    return py::make_tuple(out, b.num_rows, b.num_player_rows);
+  }
+  py::tuple server_stats() {
+    uint64_t a = 0, b = 0, c = 0;
+    int64_t d = 0;
+    epy::check(ep_pool_server_stats(pool, &a, &b, &c, &d));
+    return py::make_tuple(a, b, c, d);
+  }
+
   void rollout(int T, const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims,
                const std::vector<int64_t>& strides) {
     if (ptrs.size() != 5 || dims.size() != 5 || strides.size() != 5)
@@ -328,6 +361,9 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_recv_on_stream", &DummyPool::recv_on_stream, py::arg("stream") = 0)
       .def("_send_device", &DummyPool::send_device)
       .def("_step_device", &DummyPool::step_device)
+      .def("_step_begin", &DummyPool::step_begin)
+      .def("_step_end", &DummyPool::step_end)
+      .def("_server_stats", &DummyPool::server_stats)
       .def("_rollout", &DummyPool::rollout)
       .def("_episode_stats", &DummyPool::episode_stats)
       .def("_checkpoint_save", &DummyPool::checkpoint_save)

@@ -161,15 +161,49 @@ int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
  * by ep_pool_recv(EP_MEM_DEVICE) (envpool.py:135-142 step() = send + recv), as ONE call. For a sync
  * pool stepped as a whole (every leading dim == num_envs, num_envs a multiple of 256, list_action
  * 16-byte aligned, nothing else outstanding) no kernel is launched at all: a resident kernel of the
- * pool (one workgroup per CU) waits on a doorbell in host-mapped memory, steps the envs and answers
- * in a word the host spins on - one launch costs more than the step itself on this platform. The
- * resident kernel is bound to the three action arrays it was started for (a step with other
- * pointers restarts it), leaves by itself after about 50 ms without a step, and is stopped by any
+ * pool (one workgroup per CU) waits on a doorbell - a word of device memory that the host writes
+ * through the PCIe BAR - steps the envs and answers in words of host memory the host spins on; one
+ * launch costs more than the step itself on this platform. The resident kernel is bound to the three
+ * action arrays it was started for (a step with other pointers restarts it) and is stopped by any
  * other entry point of the pool; results are those of send + recv, views valid as for
  * ep_pool_recv(EP_MEM_DEVICE). Every other case takes the send + recv path. No counterpart in the
- * reference beyond step() itself. */
+ * reference beyond step() itself.
+ *
+ * HAZARD - device-wide synchronisation. While the resident kernel sits on the GPU, anything that
+ * waits for the whole device (hipDeviceSynchronize, torch.cuda.synchronize(), hipFree / hipMalloc
+ * of some sizes, creating or destroying another pool) waits for that kernel to leave, and a kernel
+ * enqueued on a stream that shares a hardware queue with the pool's server stream (a process has 4
+ * by default, GPU_MAX_HW_QUEUES) can be held behind it the same way. The pool bounds that wait: an
+ * idle watchdog (a host thread per pool that has used the server) stops the kernel once no step
+ * has come for about ten times the gap between the last two steps, at least 200 us and at most
+ * 50 ms, and a caller that keeps running into it (idle stops in a row) is served by the
+ * launch-per-step path for the next 8, 16, ... 1024 steps before the server is tried again - so a
+ * loop that synchronises the device after every step pays one stall of about 200 us now and then
+ * and otherwise the 13 us of send + recv. Use stream-scoped waits (hipStreamSynchronize,
+ * hipEventSynchronize, torch.cuda.current_stream().synchronize()) between steps to keep the
+ * 4-5 us path; ep_pool_sync stops the server explicitly. It also occupies one workgroup slot
+ * (256 threads, 12 KB of LDS) on every CU next to the caller's own kernels. */
 int ep_pool_step(ep_pool* pool, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims,
                  ep_batch* out);
+
+/* ep_pool_step in two halves, for a caller that steps several pools at once (one per GPU behind
+ * one front-end: ring every pool's doorbell, then wait for each): begin = the send half (rings the
+ * resident kernel, or enqueues the step kernel where the server does not apply), end = the blocking
+ * recv half. Between the two, every other entry point of THIS pool is refused (EP_ERR_INVALID) when
+ * the server was rung. ep_pool_step(...) == begin + end. */
+int ep_pool_step_begin(ep_pool* pool, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims);
+int ep_pool_step_end(ep_pool* pool, ep_batch* out);
+
+/* Counters of the resident step server since pool creation: kernels launched, times the idle
+ * watchdog stopped it, steps it served (the others took the launch path), and its current idle
+ * limit in microseconds. Any pointer may be NULL. */
+int ep_pool_server_stats(ep_pool* pool, uint64_t* launches, uint64_t* idle_stops, uint64_t* steps_served,
+                         int64_t* idle_limit_us);
+/* Diagnostic (pools created with EP_SERVER_TRACE=1 in the environment): stops the server and copies,
+ * per workgroup of its last launch, four timestamps of the last step it served (100 MHz device wall
+ * clock: doorbell seen, first tile staged, stores drained, counted in) into out[4 * workgroup + i].
+ * Returns minus the number of workgroups written (0: none), or a positive status code. */
+int ep_pool_server_trace(ep_pool* pool, uint64_t* out, int32_t max_workgroups);
 
 /* How long ep_pool_recv / ep_pool_recv_many wait for env-steps that have not been sent yet:
  * < 0 (the default) for ever, as the reference does (a single-threaded caller that receives more

@@ -56,6 +56,52 @@ def test_sharded_sync_pool_matches_one_big_oracle():
   assert r.shape == (K * n,) and (c >= 0).all()
 
 
+def test_config4_full_size_eight_shards_match_one_oracle():
+  """BASELINE config 4 at its own size in the drop-in form: make("Dummy-v0", num_envs=524288,
+  num_shards=8) - here all eight shard pools on the one GPU of the box - against ONE 524 288-env
+  oracle pool: reset, then sends of every env in ascending order, permuted, one shard's envs only
+  and an ascending subset; row i = position i of the SENT env_id array (async_envpool.h:57-80,
+  state_buffer.h:92-95), seeds from the GLOBAL id (env.h:94). Then the episode statistics against
+  the env's closed form."""
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  K, n = 8, 65536
+  G = K * n
+  seed = 3 - G // 2          # L = max(1, seed + id): half the envs have one-step episodes, the rest 4, 5, 6, ...
+  env = envpool_amd.make("Dummy-v0", "raw", num_envs=G, seed=seed, num_shards=K, shard_devices=[0] * K)
+  one = DummyOracle(num_envs=G, seed=seed)
+  ids = np.arange(G, dtype=np.int32)
+  rng = np.random.default_rng(4)
+  sends = np.zeros(G, dtype=np.int64)   # per env: sends since the reset
+
+  def same(ctx):
+    got, want = env._recv(), one._recv()
+    assert_batches_equal(got, want, ctx)
+
+  env._reset(ids); one._reset(ids); same("reset")
+  plan = ["ascending", "permuted", "ascending", "one shard", "subset", "ascending", "permuted", "ascending"]
+  for t, kind in enumerate(plan):
+    if kind == "ascending":
+      sel = ids
+    elif kind == "permuted":
+      sel = rng.permutation(ids)
+    elif kind == "one shard":
+      sel = ids[5 * n:6 * n]
+    else:
+      sel = np.sort(rng.choice(G, size=G // 3, replace=False)).astype(np.int32)
+    pe = sel + (rng.random(sel.size) < 0.05).astype(np.int32)   # a few rows name another env: obs:raw[:,1] = 0
+    a = dummy_action(sel, players_env_id=pe)
+    env._send(a); one._send(a); same(f"send {t} ({kind})")
+    sends[sel] += 1
+  ret, length, count = env._episode_stats()
+  L = np.maximum(1, seed + ids.astype(np.int64))
+  want_count = (sends + 1) // (L + 1)
+  assert count.tolist() == want_count.tolist()
+  assert length.tolist() == np.where(want_count > 0, L, 0).tolist()
+  assert not ret.any()
+  env.close() if hasattr(env, "close") else None
+
+
 def test_sharded_async_pool_config5_shape():
   """Config 5's shape scaled down: async, batch_size = num_envs / 2, K shards each with
   batch_size / K. Per env the rows equal those of one big pool (sets keyed by info:env_id)."""

@@ -77,6 +77,52 @@ def test_sync_pool_rows_in_sent_order(threads):
   pool.close(); eng.close()
 
 
+def test_sync_pool_config3_shape():
+  """BASELINE config 3 as a POOL at its own size: 1024 envs, sync, 4 workers. Resets, full sends
+  and partial sends sized so that batches go to the encoder in 1, 2, 3 and 4 parts
+  (ygo_pool.hip: parts of at least 128 rows, at most 4: ep_ygo_commit_slot_rows); every row against
+  the oracle's encoding of the engine model's state (ygopro.h:1828-1893), rows in SENT order
+  (async_envpool.h:57-80, state_buffer.h:92-95)."""
+  from tools import ygo_synth
+  N = 1024
+  cfg = capi_ygo.default_config(max_batch=N, ring_depth=0)
+  table = ygo_synth.make_table(1000, seed=0)
+  eng = ygo_synth.SynthEngine(cfg, table, N, seed=11)
+  model = ygo_synth.EnginePoolModel(cfg, table, N, seed=11)
+  pool = capi_ygo.YgoPoolC(cfg, eng.engine(), N, N, table, len(table), num_threads=4)
+  assert pool.num_threads == 4
+  pool.set_recv_timeout(60000)
+  rng = np.random.default_rng(33)
+  ids = np.arange(N, dtype=np.int32)
+  # (rows, forced reset): 1024 / 700 / 520 -> 4 parts, 400 -> 3, 300 -> 2, 130 / 17 -> 1
+  plan = [(N, True), (N, False), (300, False), (N, False), (130, False), (700, False), (400, True), (520, False),
+          (17, False), (N, False)]
+  checked = 0
+  for it, (n, forced) in enumerate(plan):
+    sel = ids if n == N and it % 2 == 0 else rng.permutation(N)[:n].astype(np.int32)
+    if forced:
+      pool.reset(sel)
+      raws = [model.advance(int(e)) for e in sel]
+    else:
+      act = rng.integers(0, 16, size=sel.size).astype(np.int32)
+      pool.send(sel, act)
+      raws = [model.advance(int(e), int(a)) for e, a in zip(sel, act)]
+    out = pool.recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+    assert out[0].shape[0] == n and out[0].tolist() == sel.tolist() and pool.last_env_ids().tolist() == sel.tolist()
+    want, status = _expect_rows(cfg, table, raws)
+    for k in range(NK):
+      assert np.asarray(out[k]).shape == np.asarray(want[k]).shape, (it, k)
+    good = np.flatnonzero(np.asarray(status) == 0)
+    for k in range(NK):
+      a, b = np.asarray(out[k])[good], np.asarray(want[k])[good]
+      if a.tobytes() != b.tobytes():
+        bad = [int(j) for j in good if np.asarray(out[k][j]).tobytes() != np.asarray(want[k][j]).tobytes()]
+        raise AssertionError(f"send {it} ({n} rows): key {k} differs in rows {bad[:8]} (envs {[int(sel[j]) for j in bad[:8]]})")
+    checked += good.size
+  assert checked > 0.9 * sum(n for n, _ in plan)
+  pool.close(); eng.close()
+
+
 @pytest.mark.parametrize("threads", [1, 6])
 def test_async_pool_config5_shape(threads):
   """BASELINE config 5 per GPU (1024 envs, batches of 512) as a POOL: reset all, then keep sending

@@ -114,6 +114,18 @@ def test_noalloc_matches_pool(P, N, B, n2):
     o2 = noalloc(rest, sub2, penv, a2[2], False)
     both = [None if x is None else np.concatenate([x, y]) for x, y in zip(o1, o2)]
     compare(both, want2, "smaller calls")
+  if P > 1:
+    # a multi-player step that brings NO player rows, right after steps that did: every env must
+    # see action_num = 0 (obs:raw[:,1]), not the previous call's histogram left in the scratch
+    empty = np.zeros(0, dtype=np.int32)
+    a = dummy_action(ids, players_env_id=empty)
+    g._send(a)
+    want3 = _pool_batches(g, N)
+    got3 = noalloc(N, ids, empty, a[2], False)
+    compare(got3, want3, "step without player rows")
+    raw = np.asarray(got3[8])
+    stepped = raw[:, 0] != 0                    # rows of envs that stepped (a reset writes state 0)
+    assert stepped.any() and not raw[stepped, 1].any()
   g.close()
 
 
@@ -138,3 +150,21 @@ def test_noalloc_rejects_oversize_and_bad_arguments():
   rc = L.ep_dummy_send_noalloc(C.byref(cfg), x.data_ptr(), 9, x.data_ptr(), 9, x.data_ptr(), x.data_ptr(), 1, arr, 12,
                                x.data_ptr(), None)
   assert rc == capi.EP_ERR_INVALID  # output arrays hold 8 rows
+  # obs:raw laid out for another state_num would be overrun by the row stores: refused
+  st = torch.zeros(32, dtype=torch.int32, device=dev)
+  ids8 = torch.arange(8, dtype=torch.int32, device=dev)
+  res = torch.zeros(4, dtype=torch.int32, device=dev)
+  rc = L.ep_dummy_send_noalloc(C.byref(cfg), st.data_ptr(), 8, ids8.data_ptr(), 0, None, None, 1, arr, 12,
+                               res.data_ptr(), None)
+  assert rc == 0, L.ep_last_error()
+  torch.cuda.synchronize()
+  arr[8].shape[1] = 12
+  rc = L.ep_dummy_send_noalloc(C.byref(cfg), x.data_ptr(), 8, x.data_ptr(), 8, x.data_ptr(), x.data_ptr(), 1, arr, 12,
+                               x.data_ptr(), None)
+  assert rc == capi.EP_ERR_INVALID and b"state_num" in L.ep_last_error()
+  arr[8].shape[1] = 10
+  arr[0].ndim = 2
+  rc = L.ep_dummy_send_noalloc(C.byref(cfg), x.data_ptr(), 8, x.data_ptr(), 8, x.data_ptr(), x.data_ptr(), 1, arr, 12,
+                               x.data_ptr(), None)
+  assert rc == capi.EP_ERR_INVALID
+  torch.cuda.synchronize()

@@ -97,7 +97,6 @@ int main(int argc, char** argv) {
     printf("send+recv per step: send %.2f  recv %.2f  total %.2f us (medians of 1800)\n", median(t_send), median(t_recv),
            median(t_send) + median(t_recv));
   }
-#ifdef HAVE_EP_POOL_STEP
   {
     const void* a1[5] = {d_ids, d_ids, d_la, d_ids, d_ids};
     std::vector<double> t_step;
@@ -110,8 +109,59 @@ int main(int argc, char** argv) {
     std::sort(t_step.begin(), t_step.end());
     printf("ep_pool_step per step: median %.2f  p10 %.2f  p90 %.2f us\n", t_step[t_step.size() / 2], t_step[t_step.size() / 10],
            t_step[t_step.size() * 9 / 10]);
+    uint64_t launches = 0, stops = 0, served = 0;
+    int64_t limit = 0;
+    CK(ep_pool_server_stats(p, &launches, &stops, &served, &limit));
+    printf("  server: %llu launches, %llu idle stops, %llu steps served, idle limit %lld us\n", (unsigned long long)launches,
+           (unsigned long long)stops, (unsigned long long)served, (long long)limit);
+    if (getenv("EP_SERVER_TRACE")) {
+      // where a step's time goes on the device: per workgroup seen -> staged -> drained -> counted
+      for (int rep = 0; rep < 3; ++rep) {
+        for (int r = 0; r < 50; ++r) CK(ep_pool_step(p, 5, a1, dims, &b));
+        static uint64_t tr[4 * 1024];
+        const int n = -ep_pool_server_trace(p, tr, 1024);
+        if (n <= 0) break;
+        uint64_t s0 = ~0ull, s1 = 0, d1 = 0, c1 = 0;
+        double w01 = 0, w12 = 0, w23 = 0;
+        for (int g = 0; g < n; ++g) {
+          s0 = std::min(s0, tr[4 * g]); s1 = std::max(s1, tr[4 * g]);
+          d1 = std::max(d1, tr[4 * g + 2]); c1 = std::max(c1, tr[4 * g + 3]);
+          w01 += (double)(tr[4 * g + 1] - tr[4 * g]); w12 += (double)(tr[4 * g + 2] - tr[4 * g + 1]);
+          w23 += (double)(tr[4 * g + 3] - tr[4 * g + 2]);
+        }
+        printf("  trace (%d workgroups, 10 ns ticks): doorbell seen over %.2f us; first seen -> last drained %.2f us, -> last counted %.2f us;"
+               " per workgroup: seen->staged %.2f, staged->drained %.2f, drained->counted %.2f us\n", n, (s1 - s0) * 0.01,
+               (d1 - s0) * 0.01, (c1 - s0) * 0.01, w01 / n * 0.01, w12 / n * 0.01, w23 / n * 0.01);
+      }
+    }
+    // begin / end halves timed apart
+    std::vector<double> t_b, t_e;
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      CK(ep_pool_step_begin(p, 5, a1, dims));
+      const double a1t = now_us();
+      CK(ep_pool_step_end(p, &b));
+      const double a2 = now_us();
+      t_b.push_back(a1t - a0); t_e.push_back(a2 - a1t);
+    }
+    printf("ep_pool_step_begin %.2f + ep_pool_step_end %.2f us (medians)\n", median(t_b), median(t_e));
+    // the caller synchronises the whole device before every step (round 2: up to 50 ms each)
+    std::vector<double> t_sync;
+    for (int r = 0; r < 1200; ++r) {
+      const double a0 = now_us();
+      (void)hipDeviceSynchronize();
+      CK(ep_pool_step(p, 5, a1, dims, &b));
+      t_sync.push_back(now_us() - a0);
+    }
+    double sum = 0;
+    for (double v : t_sync) sum += v;
+    std::sort(t_sync.begin(), t_sync.end());
+    CK(ep_pool_server_stats(p, &launches, &stops, &served, &limit));
+    printf("hipDeviceSynchronize + ep_pool_step: mean %.2f  median %.2f  p99 %.2f  max %.2f us\n", sum / t_sync.size(),
+           t_sync[t_sync.size() / 2], t_sync[t_sync.size() * 99 / 100], t_sync.back());
+    printf("  server: %llu launches, %llu idle stops, %llu steps served\n", (unsigned long long)launches, (unsigned long long)stops,
+           (unsigned long long)served);
   }
-#endif
   ep_pool_destroy(p);
   return 0;
 }
