@@ -183,8 +183,18 @@ def main():
     if rc != 0:
       raise RuntimeError(L.ep_last_error().decode())
 
+  # How the batches of a rollout are handed out inside the timed region. "stream" (default): as
+  # device views ordered on the pool's stream (ep_pool_recv_many_on_stream: what a consumer that
+  # lives on the GPU gets; the host waits for nothing until the closing synchronize, which waits for
+  # every kernel of the region). "blocking": ep_pool_recv_many, the host waits for each rollout's
+  # completion event first (what round 1 and 2 timed; measured beside it below).
+  recv_mode = {"v": os.environ.get("EP_BENCH_RECV", "stream")}
+
   def recv_n(n):
-    check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, n, batches))
+    if recv_mode["v"] == "stream":
+      check(L.ep_pool_recv_many_on_stream(h, None, n, batches))
+    else:
+      check(L.ep_pool_recv_many(h, capi.EP_MEM_DEVICE, n, batches))
 
   # BASELINE config 4 / SURVEY.md 8(d): "every K=64 steps RCCL all-gather of (return, length) per
   # rank on a side stream". The pool snapshots its statistics on its own stream; the side stream
@@ -248,13 +258,12 @@ def main():
       check(L.ep_pool_rollout(h, chunks[i], 5, ptrs, dims, strides))  # next rollout queued ...
       recv_n(chunks[i - 1])                                           # ... while this one is received
       exchange_stats(chunks[i - 1])
-    recv_n(chunks[-1])
+    recv_n(chunks[-1])   # waits for the last launch's completion event: nothing of the pool's is left running
     p2 = time.perf_counter()
     exchange_stats(chunks[-1])
-    check(L.ep_pool_sync(h))
-    if breakdown:
-      phases.update(first_rollout_call_us=(p1 - p0) * 1e6, until_last_recv_us=(p2 - p1) * 1e6,
-                    sync_us=(time.perf_counter() - p2) * 1e6)
+    # (round 2 called ep_pool_sync here; the recv above has already waited for the last launch, and
+    # the closing barrier synchronises the device: the call only cost host time inside the region)
+    phases.update(first_rollout_call_us=(p1 - p0) * 1e6, until_last_recv_us=(p2 - p1) * 1e6, region_t0=p0, region_t2=p2)
 
   # reset all envs (forced reset of every env; sync-mode reset())
   check(L.ep_pool_reset(h, env_id.data_ptr(), N, capi.EP_MEM_DEVICE))
@@ -284,7 +293,7 @@ def main():
   R = max(1, args.repeats)
   # The K-step region, R times; each run is bracketed by barrier + synchronize on both sides and
   # times exactly K lockstep steps. The line reports the MEDIAN run (max over ranks per run).
-  walls, kern, exch_in_run = [], [], []
+  walls, kern, exch_in_run, host_phases = [], [], [], []
   REHEARSALS = 4  # untimed runs of the same region first: the pool creates its timing events in them
   for r in range(-REHEARSALS, R):
     check(L.ep_pool_set_timing(h, 1))
@@ -295,16 +304,20 @@ def main():
     run_fused(K)
     barrier()
     t1 = time.perf_counter()
+    check(L.ep_pool_sync(h))  # outside the region: deferred error words, if any, surface here
     check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
     check(L.ep_pool_set_timing(h, 0))
     if r < 0:
       continue
     walls.append(t1 - t0)
+    host_phases.append({"enter_to_first_rollout_call_returned_us": (phases["region_t0"] - t0) * 1e6 + phases["first_rollout_call_us"],
+                        "until_last_batch_received_us": phases["until_last_recv_us"],
+                        "closing_synchronize_and_barrier_us": (t1 - phases["region_t2"]) * 1e6})
     exch_in_run.append(exch["in_run"])
     kern.append((tot.value, max(1, cnt.value)))
     if breakdown and rank == 0:
       print(f"[breakdown] run {r}: wall {1e6 * (t1 - t0):.1f} us, kernel {tot.value:.1f} us in {cnt.value} launches, "
-            + ", ".join(f"{k} {v:.1f}" for k, v in phases.items()), file=sys.stderr, flush=True)
+            + ", ".join(f"{k} {v:.1f}" for k, v in host_phases[-1].items()), file=sys.stderr, flush=True)
   if dist_on:
     tmax = torch.tensor(walls, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -314,6 +327,22 @@ def main():
   elapsed = walls[med]
   kern_total_us, n_launch = kern[med]
   kern_us = kern_total_us / n_launch  # average rollout-kernel duration of the median run (HIP events)
+
+  # the same region with the host waiting for every rollout's completion before the closing
+  # synchronize (rounds 1-2's way of receiving), for comparison; rank 0's own clock
+  blocking_walls = []
+  if recv_mode["v"] == "stream" and not dist_on:
+    recv_mode["v"] = "blocking"
+    for r in range(-2, R):
+      barrier()
+      t0 = time.perf_counter()
+      run_fused(K)
+      barrier()
+      t1 = time.perf_counter()
+      check(L.ep_pool_sync(h))
+      if r >= 0:
+        blocking_walls.append(t1 - t0)
+    recv_mode["v"] = "stream"
 
   # one-launch-per-step mode, measured on rank 0's pool the same way (reported, not `value`)
   per_step = None
@@ -359,7 +388,9 @@ def main():
     per_step["resident_server"] = {
       "value": N * kss / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / kss * 1e3,
       "GBps_incl_doorbell_round_trip": ALG_BYTES_PER_ENV_STEP * N * kss / (s1 - s0) / 1e9,
-      "note": "ep_pool_step: blocking step, no kernel launch (doorbell in host-mapped memory, resident kernel, sc1 loads/stores)"}
+      "kernel_frac_of_hbm_peak_incl_doorbell_round_trip": ALG_BYTES_PER_ENV_STEP * N * kss / (s1 - s0) / 1e9 / HBM_PEAK_GBS,
+      "note": "ep_pool_step: blocking step, no kernel launch (doorbell word in device memory written through the PCIe BAR, "
+              "resident kernel, sc1 loads/stores, per-shard answer words in host memory)"}
     check(L.ep_pool_sync(h))
     # the same loop with the stream-ordered recv: batches are handed out as device views on the
     # pool's own stream (where a GPU-resident policy would run), the host never waits per step
@@ -442,13 +473,15 @@ def main():
               "kernels read the pinned staging area and write the pinned result block over PCIe themselves"}
 
   cpu = None
-  if rank == 0 and not dist_on and not args.no_cpu_baseline:
+  # (N > 1 too, on rank 0 only, with a shorter sample: the other ranks wait in a host-side barrier)
+  cpu_scale = 0.4 if dist_on else 1.0
+  if rank == 0 and not args.no_cpu_baseline:
     from oracle.dummy_oracle import DummyOracle, bench_sync_mt, bench_sync_threadpool
     o = DummyOracle(num_envs=N, seed=SEED)
     c0 = time.perf_counter()
     o.bench_sync(40)
     rate1 = 40 / (time.perf_counter() - c0)
-    n1 = int(max(100, min(20000, rate1 * 5.0)))  # ~5 s single-threaded
+    n1 = int(max(100, min(20000, rate1 * 5.0 * cpu_scale)))  # ~5 s single-threaded
     o = DummyOracle(num_envs=N, seed=SEED)
     c0 = time.perf_counter()
     o.bench_sync(n1)
@@ -461,14 +494,14 @@ def main():
     c0 = time.perf_counter()
     bench_sync_mt(N, SEED, 40, cores)
     rate_mt = 40 / (time.perf_counter() - c0)
-    n_cpu = int(max(100, min(200000, rate_mt * 10.0)))  # ~10 s on all cores
+    n_cpu = int(max(100, min(200000, rate_mt * 10.0 * cpu_scale)))  # ~10 s on all cores
     c0 = time.perf_counter()
     bench_sync_mt(N, SEED, n_cpu, cores)
     c1 = time.perf_counter()
     # the same workload through the reference's ARCHITECTURE (oracle/dummy_pool_mt.c: action queue
     # -> worker threads -> state-buffer queue, fresh zeroed buffer per batch): ~3 s per thread count
     arch = {}
-    for th in (1, cores):
+    for th in (() if dist_on else (1, cores)):
       c2 = time.perf_counter()
       bench_sync_threadpool(N, SEED, 3, th)
       arch_step_s = (time.perf_counter() - c2) / 4
@@ -491,6 +524,9 @@ def main():
                 "barrier between shards); obs:dyn kept lazy (the reference allocates O(N^2) bytes "
                 "per step there and cannot run this N at all)",
     }
+
+  if dist_on and not args.no_cpu_baseline:
+    node_barrier._host_barrier()  # ranks other than 0 wait here (blocking, gloo) while rank 0 times the CPU leg
 
   # second path of the north star: the YGOPro observation-encode tail (BASELINE.json configs[2]
   # shape: 1024 records per step through the pinned pipeline; plus a 65536-record device-resident
@@ -547,6 +583,11 @@ def main():
           "metric": "ygopro obs-encodes/s", "unit": "encodes/s", "scaling": "weak",
           "value_device_resident": world * r["large_records"] / float(tm[0].item()),
           "value_config5_host_records_pcie_inclusive": world * r["pipeline_records"] / float(tm[1].item()),
+          "roofline": {"bound": "hbm", "achieved": r["alg_bytes_per_record"] * r["records_per_launch"] / (r["large_kernel_us"] * 1e-6) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": r["alg_bytes_per_record"] * r["records_per_launch"] / (r["large_kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": None, "kernel": "ygo_encode", "kernel_us": r["large_kernel_us"],
+                       "alg_bytes_per_record": r["alg_bytes_per_record"], "note": "rank 0's kernel, HIP events, outside the timed region"},
           "config5_async_ring": {"producer_threads_per_gpu": 4, "batches_per_s_all_gpus": float(ring[0].item()),
                                  "gpu_time_hidden_behind_emission_mean": float(ring[1].item()) / world,
                                  "rank0": r["ring_4_threads"]},
@@ -562,12 +603,21 @@ def main():
     L.ep_pool_last_rollout_kernel.restype = C.c_char_p
     L.ep_pool_last_rollout_kernel.argtypes = [C.c_void_p]
     rollout_kernel = L.ep_pool_last_rollout_kernel(h).decode()
-    traffic = None
+    # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their
+    # own). What the line carries is the per-launch figure of the committed profile whose launch
+    # shape matches the timed region's (every launch T steps, or one launch of K steps), labelled as
+    # such; null when no profiled shape matches.
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
       try:
-        # measured with rocprofv3 --pmc at T=64 (profiles/): bytes scale with the steps per launch
-        traffic = json.load(open(pmc_path))["rollout_hbm_bytes_per_env_step"] * N * K / n_launch
+        pmc = json.load(open(pmc_path))
+        shape = T if K % T == 0 else (K if K < T else None)
+        key_f, key_w = f"rollout_fetch_bytes_per_launch_T{shape}", f"rollout_write_bytes_per_launch_T{shape}"
+        if shape is not None and key_f in pmc and key_w in pmc:
+          traffic = pmc[key_f] + pmc[key_w]
+          traffic_source = (f"profiled constant, not measured in this run: {pmc.get('source', 'profiles/pmc_latest.json')}; "
+                            f"FETCH_SIZE (x2, gfx950) + WRITE_SIZE per {shape}-step launch of {N} envs")
       except Exception:
         traffic = None
     # K steps in n_launch launches (T steps each, the last one possibly shorter): per-launch figures
@@ -579,6 +629,11 @@ def main():
       "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
       "repeats": R, "clock_warm_launches": CLOCK_WARM_LAUNCHES, "untimed_rehearsals": REHEARSALS,
       "ms_per_step_all_runs": [w / K * 1e3 for w in walls],
+      "host_phases_of_median_run_us": host_phases[med],
+      "batches_handed_out": ("stream-ordered device views (ep_pool_recv_many_on_stream); the closing synchronize is the region's only host wait"
+                             if recv_mode["v"] == "stream" else "ep_pool_recv_many: the host waits for each rollout's completion event"),
+      **({"value_with_blocking_recv": world * N * K / sorted(blocking_walls)[len(blocking_walls) // 2],
+          "ms_per_step_with_blocking_recv": sorted(blocking_walls)[len(blocking_walls) // 2] / K * 1e3} if blocking_walls else {}),
       **({"stats_exchanges_in_each_run": exch_in_run, "stats_exchanges_in_median_run": exch_in_run[med],
           "stats_exchanges_total": exch["count"],
           "barrier": os.environ.get("EP_BENCH_BARRIER", "shared-memory generation barrier (one node)")} if dist_on else {}),
@@ -593,7 +648,7 @@ def main():
       },
       "roofline": {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "kernel": rollout_kernel, "kernel_us": kern_us, "launches": n_launch,
         "alg_bytes_per_launch": alg_launch,
       },

@@ -43,7 +43,7 @@ SYMBOLS = [
   "ep_pool_num_envs", "ep_pool_batch_size", "ep_pool_ring_depth", "ep_pool_is_sync",
   "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
   "ep_last_error", "ep_version", "ep_dummy_send_noalloc", "ep_pool_step", "ep_pool_last_rollout_kernel",
-  "ep_pool_step_begin", "ep_pool_step_end", "ep_pool_server_stats", "ep_pool_server_trace",
+  "ep_pool_step_begin", "ep_pool_step_end", "ep_pool_server_stats", "ep_pool_server_trace", "ep_pool_recv_many_on_stream",
 ]
 
 _bound = None
@@ -61,6 +61,7 @@ def lib():
     L.ep_pool_recv.argtypes = [vp, i32, C.POINTER(Batch)]
     L.ep_pool_recv_many.argtypes = [vp, i32, i32, C.POINTER(Batch)]
     L.ep_pool_recv_on_stream.argtypes = [vp, vp, C.POINTER(Batch)]
+    L.ep_pool_recv_many_on_stream.argtypes = [vp, vp, i32, C.POINTER(Batch)]
     L.ep_pool_set_recv_timeout.argtypes = [vp, i64]
     L.ep_pool_step.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(Batch)]
     L.ep_pool_step_begin.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]

@@ -155,6 +155,10 @@ struct ep_pool {
   bool wd_started = false, wd_quit = false;
   std::chrono::steady_clock::time_point last_ring{};
   int64_t idle_limit_us = 200;
+  bool counted_on_device = false;
+  bool server_shared_ok = false;  // EP_SERVER_SHARED_DEVICE=1
+  bool server_fresh = false;    // started, and no warm step served yet
+  bool gap_tainted = true;      // the time since the last step holds an idle stop (or nothing yet): not a cadence to learn from
   uint32_t idle_streak = 0;     // idle stops in a row with no warm step between them
   uint32_t server_backoff = 0;  // steps that take the launch path before the server is tried again
   uint64_t server_launches = 0, server_idle_stops = 0, server_steps = 0;
@@ -420,6 +424,18 @@ uint32_t next_stamp(ep_pool* p) {  // stamp of the launch about to be enqueued: 
 // Asks a running server to leave and waits until its kernel has ended. Every entry point that
 // enqueues work on the pool's streams or reads the env state calls this first: while the server
 // runs, it alone owns the env records and the ring.
+// Resident servers running per device in this process: each holds a (low-priority) hardware queue.
+std::atomic<int> g_servers_running[64];
+std::atomic<int> g_pools_on_device[64];  // live pools per device in this process
+int max_servers_per_device() {  // EP_SERVER_MAX_PER_DEVICE (read when a pool asks to start its server)
+  const char* e = getenv("EP_SERVER_MAX_PER_DEVICE");
+  return e ? std::max(0, atoi(e)) : 1;
+}
+// Several pools on ONE GPU (a sharded front-end rehearsed on a one-GPU box): a resident kernel
+// beside other pools' launches made every step slower, not faster (4 shards of 16 384 envs:
+// 89 us per front-end step with launches only, 142-177 us with one to four servers resident,
+// profiles/r03/sharded_step_time.txt), so the server is for a pool that has its GPU to itself -
+// the deployment it is meant for. EP_SERVER_SHARED_DEVICE=1 at pool creation lifts that (measurements, tests).
 void ring_bell(ep_pool* p, unsigned long long v) {
   if (p->bar_bell) {
     // device memory through the BAR: a write-combining mapping, so the store is pushed out at once
@@ -444,6 +460,7 @@ int server_stop(ep_pool* p) {
   HIP_TRY(hipStreamSynchronize(p->server_stream));  // (the kernel leaves within a poll of seeing the flag, or has left already)
   ring_bell(p, (unsigned long long)p->server_seq);
   p->server_running = false;
+  g_servers_running[p->device & 63].fetch_sub(1);
   return EP_OK;
 }
 
@@ -452,12 +469,19 @@ void server_watchdog(ep_pool* p) {
   std::unique_lock<std::mutex> lk(p->mu);
   while (!p->wd_quit) {
     if (!p->server_running) { p->wd_cv.wait(lk); continue; }
-    const auto limit = std::chrono::microseconds(p->idle_limit_us);
+    // (a caller that keeps running into idle stops gets half the patience each time: the stall of
+    // one that synchronises the device after every step is this limit)
+    // A server that has just been started gets 2 ms before its first step-to-step gap is judged:
+    // starting one costs some 50 us, and a front-end that starts several (one per shard) in a row
+    // would otherwise find the first ones stopped again before its next step.
+    const auto limit = std::chrono::microseconds(
+        std::max<int64_t>(p->server_fresh ? 2000 : 200, p->idle_limit_us >> std::min(p->idle_streak, 8u)));
     if (p->step_mode == 1) { p->wd_cv.wait_for(lk, limit); continue; }
     const auto deadline = p->last_ring + limit;
     if (std::chrono::steady_clock::now() < deadline) { p->wd_cv.wait_until(lk, deadline); continue; }
     if (hipSetDevice(p->device) != hipSuccess || server_stop(p) != EP_OK) { p->wd_cv.wait_for(lk, std::chrono::milliseconds(50)); continue; }
     ++p->server_idle_stops;
+    p->gap_tainted = true;
     // a caller that keeps letting the server run idle (one that synchronises the device after every
     // step, or steps rarely) is served by the launch path for a while: 8, 16, ... 1024 steps
     p->idle_streak = std::min(p->idle_streak + 1, 8u);
@@ -509,6 +533,8 @@ int server_start(ep_pool* p, const void* const* arrs) {
   else hipLaunchKernelGGL(epk::dummy_step_server<0>, dim3(n_wg), dim3(epk::kBlock), 0, p->server_stream, a);
   HIP_TRY(hipGetLastError());
   p->server_running = true;
+  g_servers_running[p->device & 63].fetch_add(1);
+  p->server_fresh = true;
   p->server_shards = p->server_two_level ? 1 : std::min(n_wg, epk::kServerShards);
   ++p->server_launches;
   p->last_ring = std::chrono::steady_clock::now();
@@ -862,7 +888,19 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     HIP_TRY(hipEventCreateWithFlags(&p->stage_free[a], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->stage_copied[a], hipEventDisableTiming));
   }
-  HIP_TRY(hipStreamCreateWithFlags(&p->server_stream, hipStreamNonBlocking));
+  {
+    // The resident kernel occupies the hardware queue its stream is mapped to for as long as it
+    // runs, and a process has few of them (GPU_MAX_HW_QUEUES, 4 by default) shared by all its
+    // streams: anything enqueued on a stream that shares that queue would sit behind the server
+    // until it leaves. The runtime keeps a separate set of hardware queues per stream priority, so
+    // the server stream is created with the LOWEST priority: it then shares queues only with other
+    // pools' server streams (EP_SERVER_MAX_PER_DEVICE of which run at once), never with the
+    // pool's own streams, torch's or the caller's.
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (least != greatest) HIP_TRY(hipStreamCreateWithPriority(&p->server_stream, hipStreamNonBlocking, least));
+    else HIP_TRY(hipStreamCreateWithFlags(&p->server_stream, hipStreamNonBlocking));
+  }
   HIP_TRY(hipHostMalloc((void**)&p->h_ctl, sizeof(epk::ServerCtl), hipHostMallocMapped));
   memset(p->h_ctl, 0, sizeof(epk::ServerCtl));
   HIP_TRY(hipHostGetDevicePointer((void**)&p->d_ctl, p->h_ctl, 0));
@@ -887,6 +925,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
 #endif
       }
     if (const char* sj = getenv("EP_SERVER_JOIN")) p->server_two_level = sj[0] == '2';
+    if (const char* sd = getenv("EP_SERVER_SHARED_DEVICE")) p->server_shared_ok = sd[0] == '1';
     if (const char* sp = getenv("EP_SERVER_PAUSE")) p->spin_pause = sp[0] == '1';
     const char* sb = getenv("EP_SERVER_BAR");
     if (large_bar && !(sb && sb[0] == '0')) {
@@ -907,6 +946,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->blocks = std::make_shared<HostBlocks>();
   p->blocks->bytes = p->slot_stride;
   HIP_TRY(hipStreamSynchronize(p->stream));
+  g_pools_on_device[p->device & 63].fetch_add(1);
+  p->counted_on_device = true;
   *out = p.release();
   return EP_OK;
 }
@@ -921,6 +962,7 @@ int ep_pool_destroy(ep_pool* p) {
   }
   p->step_mode = 0;
   (void)server_stop(p);
+  if (p->counted_on_device) g_pools_on_device[p->device & 63].fetch_sub(1);
   (void)hipFree(p->bar_bell);
   (void)hipFree(p->d_server_trace);
   (void)hipStreamSynchronize(p->stream);
@@ -1379,6 +1421,17 @@ int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
   return recv_locked(p, EP_MEM_DEVICE, out, lk, &cs);
 }
 
+int ep_pool_recv_many_on_stream(ep_pool* p, void* consumer_stream, int32_t n, ep_batch* out) {
+  if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
+  std::unique_lock<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : p->stream;
+  for (int i = 0; i < n; ++i)
+    if ((rc = recv_locked(p, EP_MEM_DEVICE, out + i, lk, &cs))) return rc;
+  return EP_OK;
+}
+
 int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
   if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
@@ -1412,6 +1465,23 @@ int ep_pool_step_begin(ep_pool* p, int32_t n_arrays, const void* const* arrays, 
                          !((uintptr_t)arrays[2] & 15);
     const bool idle = p->alloc_count == p->done_ptr * (uint64_t)p->B && p->stepping_env_num == 0;
     bool serve = p->use_server && !p->force_generic && p->is_sync && whole && aligned && idle && p->N % epk::kBlock == 0 && !p->poisoned;
+    const auto now = std::chrono::steady_clock::now();
+    if (serve) {
+      // the server's patience follows the caller's cadence: about ten gaps between consecutive
+      // steps (whichever path served them), 200 us .. 50 ms. A gap that holds an idle stop is not a
+      // cadence: the wait of a caller that synchronises the device is the idle limit itself, and
+      // learning from it would lengthen the next one.
+      if (!p->gap_tainted) {
+        const int64_t gap = std::chrono::duration_cast<std::chrono::microseconds>(now - p->last_ring).count();
+        p->idle_limit_us = std::min<int64_t>(50000, std::max<int64_t>(200, 10 * gap));
+      }
+      p->gap_tainted = false;
+      p->last_ring = now;
+    }
+    if (serve && !p->server_running &&
+        (g_servers_running[p->device & 63].load() >= max_servers_per_device() ||
+         (g_pools_on_device[p->device & 63].load() > 1 && !p->server_shared_ok)))
+      serve = false;  // (several pools on one GPU: the launch path)
     if (serve && !p->server_running && p->server_backoff > 0) {
       --p->server_backoff;  // the server ran idle lately (server_watchdog): the launch path for now
       serve = false;
@@ -1422,6 +1492,7 @@ int ep_pool_step_begin(ep_pool* p, int32_t n_arrays, const void* const* arrays, 
         // its own poll limit ran out (the watchdog should have stopped it long before): wait for the kernel to end
         HIP_TRY(hipStreamSynchronize(p->server_stream));
         p->server_running = false;
+        g_servers_running[p->device & 63].fetch_sub(1);
       }
       if (p->server_running && (p->server_arrays[0] != arrays[0] || p->server_arrays[1] != arrays[1] || p->server_arrays[2] != arrays[2]))
         if ((rc = server_stop(p))) return rc;  // other action arrays: the server is started again for them
@@ -1429,13 +1500,7 @@ int ep_pool_step_begin(ep_pool* p, int32_t n_arrays, const void* const* arrays, 
       if ((rc = claim_err_word(p, bi))) return rc;
       const bool warm = p->server_running;
       if (!warm && (rc = server_start(p, arrays))) return rc;
-      const auto now = std::chrono::steady_clock::now();
-      if (warm) {
-        // the server's patience follows the caller's cadence: about ten gaps, 200 us .. 50 ms
-        const int64_t gap = std::chrono::duration_cast<std::chrono::microseconds>(now - p->last_ring).count();
-        p->idle_limit_us = std::min<int64_t>(50000, std::max<int64_t>(200, 10 * gap));
-      }
-      p->last_ring = now;
+      p->last_ring = std::chrono::steady_clock::now();
       p->step_warm = warm;
       p->step_bi = bi;
       ring_bell(p, (unsigned long long)++p->server_seq);
@@ -1474,6 +1539,7 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
             // the kernel's own poll limit ran out as the doorbell rang: wait for the kernel to end
             HIP_TRY(hipStreamSynchronize(p->server_stream));
             p->server_running = false;
+            g_servers_running[p->device & 63].fetch_sub(1);
             if (all_done()) break;
             if (p->bar_bell) {
               // (each workgroup decides for itself there: some may have served the step, some not)
@@ -1500,7 +1566,7 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
       }
       p->step_mode = 0;
       ++p->server_steps;
-      if (p->step_warm) p->idle_streak = 0;
+      if (p->step_warm) { p->idle_streak = 0; p->server_fresh = false; }
       const uint64_t bi = p->step_bi;
       const int slot = (int)(bi % (uint64_t)p->Q);
       const int status = status_of_err_bits(take_err_bits(p, err_index(p, bi)), "step");

@@ -165,13 +165,21 @@ struct DummyPool {
   }
 
   // PyEnvPool::PyRecv (py_envpool.h:230-241)
-  std::vector<py::object> recv() {
+  std::vector<py::object> recv() { return recv_impl(false).cast<std::vector<py::object>>(); }
+  // Additive: recv that never waits for rows that have not been sent yet (None then): what a
+  // front-end over several pools polls with (python/sharded.py).
+  py::object try_recv() { return recv_impl(true); }
+
+  py::object recv_impl(bool poll) {
     auto holder = std::make_shared<epy::BatchHolder>();
     int rc;
     {
       py::gil_scoped_release rel;
+      if (poll) (void)ep_pool_set_recv_timeout(pool, 0);
       rc = ep_pool_recv(pool, EP_MEM_HOST, &holder->batch);
+      if (poll) (void)ep_pool_set_recv_timeout(pool, timeout_ms);
     }
+    if (poll && rc == EP_ERR_WOULD_BLOCK) return py::none();
     const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
     if (rc != EP_OK && !batch_with_error) epy::check(rc);
     std::string deferred = batch_with_error ? ep_last_error() : "";
@@ -184,18 +192,24 @@ struct DummyPool {
     }
     ret[9] = make_dyn(py::array(ret[1]));
     if (!deferred.empty()) throw std::runtime_error(deferred);
-    return ret;
+    return py::cast(ret);
   }
 
   // Additive API: zero-copy device views, as (ptr, shape, typestr) descriptors in
   // _state_keys order (None for obs:dyn). See envpool_amd/interop.py.
-  py::tuple recv_device() {
+  py::tuple recv_device() { return recv_device_impl(false).cast<py::tuple>(); }
+  py::object try_recv_device() { return recv_device_impl(true); }
+
+  py::object recv_device_impl(bool poll) {
     ep_batch b;
     int rc;
     {
       py::gil_scoped_release rel;
+      if (poll) (void)ep_pool_set_recv_timeout(pool, 0);
       rc = ep_pool_recv(pool, EP_MEM_DEVICE, &b);
+      if (poll) (void)ep_pool_set_recv_timeout(pool, timeout_ms);
     }
+    if (poll && rc == EP_ERR_WOULD_BLOCK) return py::none();
     const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
     if (rc != EP_OK && !batch_with_error) epy::check(rc);
     std::string deferred = batch_with_error ? ep_last_error() : "";
@@ -330,7 +344,8 @@ struct DummyPool {
     epy::check(ep_pool_checkpoint_restore(pool, buf.data()));
   }
   void sync() { py::gil_scoped_release rel; epy::check(ep_pool_sync(pool)); }
-  void set_recv_timeout(int64_t ms) { epy::check(ep_pool_set_recv_timeout(pool, ms)); }
+  int64_t timeout_ms = -1;
+  void set_recv_timeout(int64_t ms) { epy::check(ep_pool_set_recv_timeout(pool, ms)); timeout_ms = ms; }
   uintptr_t stream() { return reinterpret_cast<uintptr_t>(ep_pool_stream(pool)); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
 };
@@ -358,6 +373,8 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
       // additive (no reference counterpart)
       .def("_recv_device", &DummyPool::recv_device)
+      .def("_try_recv", &DummyPool::try_recv)
+      .def("_try_recv_device", &DummyPool::try_recv_device)
       .def("_recv_on_stream", &DummyPool::recv_on_stream, py::arg("stream") = 0)
       .def("_send_device", &DummyPool::send_device)
       .def("_step_device", &DummyPool::step_device)

@@ -143,32 +143,44 @@ struct YgoPool {
 
   // PyEnvPool::PyRecv (py_envpool.h:230-241): numpy views of the pinned host block, no copy;
   // key 16 (aux:h_card_ids) is additive and returned separately
-  py::tuple recv_all() {
+  py::object recv_all_impl(bool poll) {
     auto holder = std::make_shared<epy::BatchHolder>();
     int rc;
     {
       py::gil_scoped_release rel;
+      if (poll) (void)ep_ygo_pool_set_recv_timeout(pool, 0);
       rc = ep_ygo_pool_recv(pool, EP_MEM_HOST, &holder->batch);
+      if (poll) (void)ep_ygo_pool_set_recv_timeout(pool, timeout_ms);
     }
+    if (poll && rc == EP_ERR_WOULD_BLOCK) return py::none();
     const bool batch_with_error = rc == EP_ERR_ACTION_CHECK;
     if (rc != EP_OK && !batch_with_error) epy::check(rc);
     py::list ret;
     for (int k = 0; k < holder->batch.num_keys; ++k) ret.append(view_of_any(holder, holder->batch.arrays[k]));
     return py::make_tuple(ret, batch_with_error ? std::string(ep_last_error()) : std::string());
   }
+  py::object recv_all() { return recv_all_impl(false); }
+  // Additive: recv that never waits for a batch that is not complete yet (None then): what a
+  // front-end over several pools polls with (python/sharded.py).
+  py::object try_recv_all() { return recv_all_impl(true); }
 
-  py::tuple recv_device() {
+  py::object recv_device_impl(bool poll) {
     ep_batch b;
     int rc;
     {
       py::gil_scoped_release rel;
+      if (poll) (void)ep_ygo_pool_set_recv_timeout(pool, 0);
       rc = ep_ygo_pool_recv(pool, EP_MEM_DEVICE, &b);
+      if (poll) (void)ep_ygo_pool_set_recv_timeout(pool, timeout_ms);
     }
+    if (poll && rc == EP_ERR_WOULD_BLOCK) return py::none();
     if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
     py::list out;
     for (int k = 0; k < b.num_keys; ++k) out.append(desc_any(b.arrays[k]));
     return py::make_tuple(out, b.num_rows, b.num_rows);
   }
+  py::object recv_device() { return recv_device_impl(false); }
+  py::object try_recv_device() { return recv_device_impl(true); }
 
   // info:env_id of the batch received last, from host memory (a copy: the library's array only lives
   // until the next recv)
@@ -181,7 +193,8 @@ struct YgoPool {
     return out;
   }
 
-  void set_recv_timeout(int64_t ms) { epy::check(ep_ygo_pool_set_recv_timeout(pool, ms)); }
+  int64_t timeout_ms = -1;
+  void set_recv_timeout(int64_t ms) { epy::check(ep_ygo_pool_set_recv_timeout(pool, ms)); timeout_ms = ms; }
   int num_threads() { return ep_ygo_pool_num_threads(pool); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
 
@@ -228,6 +241,8 @@ PYBIND11_MODULE(ygopro_envpool, m) {
       .def("_reset", &YgoPool::reset)
       .def("_recv_all", &YgoPool::recv_all)
       .def("_recv_device_all", &YgoPool::recv_device)
+      .def("_try_recv_all", &YgoPool::try_recv_all)
+      .def("_try_recv_device_all", &YgoPool::try_recv_device)
       .def("_last_env_ids", &YgoPool::last_env_ids)
       .def("_set_recv_timeout", &YgoPool::set_recv_timeout)
       .def("_num_threads", &YgoPool::num_threads)

@@ -210,7 +210,14 @@ class EnvPoolFrontEnd:
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
     key) or a dict of them in the shapes step() takes, `env_id` an int32 CUDA tensor or None for all
     envs in order. Returns what step() returns, as torch tensors aliasing the device ring. A sync
-    pool stepped as a whole takes no kernel launch (ep_pool_step, the pool's resident kernel)."""
+    pool stepped as a whole takes no kernel launch (ep_pool_step, the pool's resident kernel), as
+    long as the action tensors keep their addresses: pass contiguous int32 / float64 tensors and
+    reuse them (a tensor that needs a dtype or layout conversion is copied into a staging tensor the
+    pool keeps, so the addresses the resident kernel is bound to stay the same either way).
+    While that kernel sits on the GPU a device-wide wait (torch.cuda.synchronize()) between two
+    steps has to wait for it to leave - the pool's watchdog bounds that to about ten step gaps,
+    200 us at least, and falls back to launching per step for callers that keep doing it; use
+    torch.cuda.current_stream().synchronize() instead (include/envpool_amd.h, ep_pool_step)."""
     import torch
     if not hasattr(self, "_step_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
@@ -237,7 +244,13 @@ class EnvPoolFrontEnd:
       if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError(f'step_torch: action "{k}" must be a CUDA tensor')
       if t.dtype != want or not t.is_contiguous():
-        t = t.to(want).contiguous()
+        if not hasattr(self, "_torch_stage"):
+          self._torch_stage = {}
+        st = self._torch_stage.get(k)
+        if st is None or st.shape != t.shape:
+          st = self._torch_stage[k] = torch.empty(t.shape, dtype=want, device=dev)
+        st.copy_(t)
+        t = st
       keep.append(t)
       ptrs.append(t.data_ptr())
       dims.append(int(t.shape[0]))

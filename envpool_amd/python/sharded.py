@@ -1,5 +1,6 @@
 """One pool over several GPUs in ONE process: K independent shard pools behind the raw
-`_send / _recv / _reset` surface of `_DummyEnvPool` (BASELINE configs 4 and 5).
+`_send / _recv / _reset` surface of `_DummyEnvPool` / `_YGOProEnvPool` (BASELINE
+configs 4 and 5).
 
 Envs are independent (the only state the reference shares between them is the StateBuffer slot
 counters, envpool2/core/state_buffer.h:85-88), so the node-wide pool is K pools: shard r owns the
@@ -11,10 +12,18 @@ them; there is no device exchange.
   `_recv` puts the shards' rows back at the positions their envs had in the SENT `env_id` array -
   row i of the result is the env at position i of the send, exactly the single-pool contract
   (async_envpool.h:69 + state_buffer.h:92-95). One send (or reset) per recv.
-* async mode: every shard runs with batch_size / K and `_recv` concatenates one batch of each, so
-  a batch still holds batch_size env-steps (BASELINE config 5: 8192 / 4096 over 8 GPUs is 1024 /
-  512 per GPU). Rows come in shard order, then arrival order inside a shard; like the reference's
-  arrival order this is to be compared as a set keyed by `info:env_id`.
+* async mode: every shard runs with batch_size / K, and a node-wide batch is K shard batches from
+  WHICHEVER shards have one complete - several from one shard if that is who is ready - so a shard
+  whose envs are slow does not hold up the batch (the reference hands out the first batch_size
+  arrivals, state_buffer_queue.h:114-150; round 2 took one batch from every shard in turn). Shards
+  are polled in rotation (`_try_recv`); when none is ready the call naps and polls again (it never
+  sits on one shard while another may complete first). Rows come part by part, arrival order inside a
+  part; like the reference's arrival order this is to be compared as a set keyed by `info:env_id`.
+* device path (additive): `reset_torch / recv_torch / send_torch / step_torch` keep every byte on
+  the shards' GPUs. A result is a `ShardedResult`: one ordinary result per shard (or per received
+  part), each on its own device, in shard order = ascending env ids; `.cat(device)` stitches them
+  for a consumer that wants one tensor per key. A whole-pool lockstep step rings every shard's
+  resident server first and then waits for each (`ep_pool_step_begin / _end`).
 
 The shard pools come from a factory, so the fan-out / stitch logic is testable without a GPU
 (tests/test_host_cpu.py drives it with CPU oracle pools).
@@ -27,8 +36,8 @@ import numpy as np
 
 from .lazy import LazyDyn
 
-_PLAYER_KEYS = (1, 4, 5, 8, 9, 10, 11)  # state keys whose leading dim counts players, not envs
-_DYN = 9
+_DUMMY_STATE_KEYS = ("info:env_id", "info:players.env_id", "elapsed_step", "done", "reward", "discount", "step_type",
+                     "trunc", "obs:raw", "obs:dyn", "info:players.done", "info:players.id")
 
 
 def _cat_dyn(parts: List, players_env_id: np.ndarray, state_num: int):
@@ -41,13 +50,58 @@ def _cat_dyn(parts: List, players_env_id: np.ndarray, state_num: int):
   return LazyDyn(players_env_id, state_num)
 
 
+class ShardedResult(list):
+  """Per-shard (or per-part) results of a device-path call, each on its shard's GPU. `owners[i]`
+  is the shard part i came from (what `send_torch` needs to route the next actions)."""
+
+  owners: List[int]
+
+  def cat(self, device=None):
+    """One result with every leaf concatenated over the parts, on `device` (default: the first
+    part's). Parts on other GPUs are copied over (peer copies)."""
+    import torch
+
+    def leaf_device(x):
+      if isinstance(x, torch.Tensor):
+        return x.device
+      if isinstance(x, dict):
+        for v in x.values():
+          d = leaf_device(v)
+          if d is not None:
+            return d
+      elif isinstance(x, (tuple, list)):
+        for v in x:
+          d = leaf_device(v)
+          if d is not None:
+            return d
+      return None
+
+    dev = torch.device(device) if device is not None else leaf_device(self[0])
+
+    def go(xs):
+      x0 = xs[0]
+      if isinstance(x0, torch.Tensor):
+        return torch.cat([x.to(dev, non_blocking=True) for x in xs]) if len(xs) > 1 else x0.to(dev)
+      if isinstance(x0, dict):
+        return {k: go([x[k] for x in xs]) for k in x0}
+      if isinstance(x0, tuple) and hasattr(x0, "_fields"):
+        return type(x0)(*[go([x[i] for x in xs]) for i in range(len(x0))])
+      if isinstance(x0, (tuple, list)):
+        return type(x0)(go([x[i] for x in xs]) for i in range(len(x0)))
+      return x0
+
+    return go(list(self))
+
+
 class ShardedRawPool(metaclass=ABCMeta):
   """K shard pools with the raw boundary of one pool. `make_shard(rank, num_envs, batch_size,
-  env_id_offset, device)` returns an object with `_send(list)`, `_recv() -> list`, `_reset(ids)`."""
+  env_id_offset, device)` returns an object with `_send(list)`, `_recv() -> list`, `_reset(ids)`
+  and, optionally, `_try_recv()` (None when no batch is complete), `_set_recv_timeout(ms)`,
+  `close()` and the device-path methods of the pybind pools."""
 
   def __init__(self, num_envs: int, batch_size: int, max_num_players: int, state_num: int,
                num_shards: int, make_shard: Callable, devices: Optional[Sequence[int]] = None,
-               env_id_offset: int = 0):
+               env_id_offset: int = 0, state_keys: Sequence[str] = _DUMMY_STATE_KEYS):
     if num_shards < 1 or num_envs % num_shards != 0:
       raise ValueError(f"num_envs = {num_envs} is not divisible by num_shards = {num_shards}")
     batch_size = batch_size or num_envs
@@ -55,18 +109,36 @@ class ShardedRawPool(metaclass=ABCMeta):
     self._off = env_id_offset
     self._n_local = num_envs // num_shards
     self._sync = batch_size == num_envs and max_num_players == 1  # async_envpool.h:95
+    self._nkeys = len(state_keys)
+    self._dyn = list(state_keys).index("obs:dyn") if "obs:dyn" in state_keys else None
     if batch_size == num_envs:
       b_local = self._n_local
     elif batch_size % num_shards == 0:
       b_local = batch_size // num_shards
     else:
       raise ValueError(f"async sharded pool: batch_size = {batch_size} is not divisible by num_shards = {num_shards}")
+    self._b_local = b_local
     devices = list(devices) if devices is not None else list(range(num_shards))
     if len(devices) != num_shards:
       raise ValueError("one device per shard")
+    self._devices = devices
     self._shards = [make_shard(r, self._n_local, b_local, env_id_offset + r * self._n_local, devices[r])
                     for r in range(num_shards)]
     self._pending = deque()  # sync mode: per outstanding send, the positions of each shard's envs
+    self._next = 0                         # async recv: where the rotation over the shards stands
+    self._timeout_ms = -1
+    self._last_owners: List[int] = []
+
+  def close(self) -> None:
+    for s in self._shards:
+      if hasattr(s, "close"):
+        s.close()
+
+  def _set_recv_timeout(self, ms: int) -> None:
+    self._timeout_ms = ms
+    for s in self._shards:
+      if hasattr(s, "_set_recv_timeout"):
+        s._set_recv_timeout(ms)
 
   # ---- fan-out ---------------------------------------------------------------------------
   def _owner(self, env_id: np.ndarray) -> np.ndarray:
@@ -119,10 +191,11 @@ class ShardedRawPool(metaclass=ABCMeta):
     rest = [np.asarray(a) for a in action[2:]]
     if self._P == 1:
       def one(r, p):  # single player: action row i belongs to item i (env.h:115-123)
-        self._shards[r]._send([env_id[p].astype(np.int32, copy=False), penv[p], rest[0][p], rest[1][p], rest[2][p]])
+        self._shards[r]._send([env_id[p].astype(np.int32, copy=False), penv[p]] + [a[p] for a in rest])
     else:
       # players.* arrays have one row per player: a row follows the env its players.env_id names
-      # (env.h:128-132); rows that name an env outside the pool match nothing and are dropped
+      # (env.h:128-132); rows that name an env outside the pool match nothing and are dropped.
+      # (Dummy's action keys: list_action is per env, players.action / players.id per player)
       plocal = penv.astype(np.int64) - self._off
       powner = np.where((plocal >= 0) & (plocal < self._N), plocal // self._n_local, -1)
 
@@ -135,13 +208,73 @@ class ShardedRawPool(metaclass=ABCMeta):
     env_ids = np.asarray(env_ids)
     self._fan_out(env_ids, lambda r, p: self._shards[r]._reset(env_ids[p].astype(np.int32, copy=False)))
 
+  # ---- async: K shard batches from whoever is ready ----------------------------------------
+  def _gather_parts(self, try_recv: Callable) -> List:
+    """K complete shard batches, each as (shard, batch), from whichever shards have one:
+    `try_recv(shard)` returns None when that shard has no complete batch. Shards are asked in
+    rotation, starting behind the one served last, so that a shard that is always ready cannot
+    crowd the others out; when a whole sweep finds nothing the call naps (20 us, doubling up to
+    1 ms) and sweeps again - it never sits on ONE shard while another may complete first. The wait
+    for rows nobody has sent follows `_set_recv_timeout` (< 0: for ever, like the reference)."""
+    import time
+    K = self._K
+    parts: List = list(getattr(self, "_stash", []))
+    self._stash = []
+    for i, (r, _) in enumerate(parts):
+      self._on_part(r, i)
+    nap, t0 = 20e-6, None
+    while len(parts) < K:
+      progress = False
+      for _ in range(K):
+        r = self._next
+        self._next = (self._next + 1) % K
+        got = try_recv(r)
+        if got is not None:
+          parts.append((r, got))
+          self._on_part(r, len(parts) - 1)
+          progress = True
+          if len(parts) == K:
+            break
+      if progress:
+        nap, t0 = 20e-6, None
+        continue
+      if self._timeout_ms == 0:
+        break
+      now = time.monotonic()
+      t0 = now if t0 is None else t0
+      if self._timeout_ms > 0 and (now - t0) * 1e3 > self._timeout_ms:
+        break
+      time.sleep(nap)
+      nap = min(2 * nap, 1e-3)
+    if len(parts) < K:
+      # (parts already taken stay taken: hand them back through the next call)
+      self._stash = parts + getattr(self, "_stash", [])
+      raise RuntimeError(f"recv would block: {len(parts)} of {K} shard batches are complete")
+    self._last_owners = [r for r, _ in parts]
+    return parts
+
+  def _on_part(self, shard: int, index: int) -> None:
+    """Called right after shard `shard` handed out part `index` of the batch being put together
+    (index 0 starts a new batch): pools whose shards keep per-batch extras pick them up here."""
+
+  def _cat_parts(self, parts: List) -> List:
+    out = [None if k == self._dyn else np.concatenate([p[k] for _, p in parts]) for k in range(self._nkeys)]
+    if self._dyn is not None:
+      out[self._dyn] = _cat_dyn([p[self._dyn] for _, p in parts], out[1], self._S)
+    return out
+
   # ---- stitch ----------------------------------------------------------------------------
   def _recv(self) -> List:
     if not self._sync:
-      parts = [s._recv() for s in self._shards]
-      out = [None if k == _DYN else np.concatenate([p[k] for p in parts]) for k in range(len(parts[0]))]
-      out[_DYN] = _cat_dyn([p[_DYN] for p in parts], out[1], self._S)
-      return out
+      if all(hasattr(s, "_try_recv") for s in self._shards):
+        parts = self._gather_parts(lambda r: self._shards[r]._try_recv())
+      else:  # shard pools that cannot be polled: one batch of each, in turn
+        parts = []
+        for r, s in enumerate(self._shards):
+          parts.append((r, s._recv()))
+          self._on_part(r, r)
+        self._last_owners = list(range(self._K))
+      return self._cat_parts(parts)
     if not self._pending:
       return self._shards[0]._recv()  # nothing outstanding: the reference returns an empty batch
     n, pos = self._pending.popleft()
@@ -156,42 +289,52 @@ class ShardedRawPool(metaclass=ABCMeta):
         part = self._shards[r]._recv()
         if len(part[0]) != self._count(p):
           raise RuntimeError(f"shard {r} returned {len(part[0])} rows for {self._count(p)} sent envs")
-        parts.append(part)
+        parts.append((r, part))
+        self._on_part(r, len(parts) - 1)
+      self._last_owners = [r for r, _ in parts]
       if len(parts) == 1:
-        return parts[0]
-      out = [None if k == _DYN else np.concatenate([q[k] for q in parts]) for k in range(len(parts[0]))]
-      out[_DYN] = _cat_dyn([q[_DYN] for q in parts], out[1], self._S)
-      return out
-    out: List = [None] * 12
+        return parts[0][1]
+      return self._cat_parts(parts)
+    out: List = [None] * self._nkeys
     dyn_ids = None
+    self._last_owners = []
     for r, p in enumerate(pos):
       if not self._count(p):
         continue
       p = np.arange(p.start, p.stop) if isinstance(p, slice) else p
       part = self._shards[r]._recv()
+      self._last_owners.append(r)
+      self._on_part(r, len(self._last_owners) - 1)
       if len(part[0]) != p.size:
         raise RuntimeError(f"shard {r} returned {len(part[0])} rows for {p.size} sent envs")
       for k, a in enumerate(part):
-        if k == _DYN:
+        if k == self._dyn:
           continue
         if out[k] is None:
           out[k] = np.zeros((n,) + a.shape[1:], a.dtype)
         out[k][p] = a  # single player: player rows == env rows
-      if isinstance(part[_DYN], LazyDyn) or part[_DYN] is None:
+      if self._dyn is None:
+        continue
+      if isinstance(part[self._dyn], LazyDyn) or part[self._dyn] is None:
         dyn_ids = True
       else:
-        if out[_DYN] is None:
-          out[_DYN] = np.empty(n, dtype=object)
+        if out[self._dyn] is None:
+          out[self._dyn] = np.empty(n, dtype=object)
         for j, q in enumerate(p):
-          out[_DYN][q] = part[_DYN][j]
+          out[self._dyn][q] = part[self._dyn][j]
     if dyn_ids:
-      out[_DYN] = LazyDyn(out[1], self._S)
+      out[self._dyn] = LazyDyn(out[1], self._S)
     return out
 
   # ---- additive ---------------------------------------------------------------------------
   @property
   def shards(self):
     return list(self._shards)
+
+  @property
+  def last_owners(self) -> List[int]:
+    """Shard of each part of the batch `_recv` (or `recv_torch`) handed out last, in row order."""
+    return list(self._last_owners)
 
   def _episode_stats(self):
     """(return f32[N], length i32[N], count i32[N]) ordered by global env_id."""
@@ -203,21 +346,250 @@ class ShardedRawPool(metaclass=ABCMeta):
       s._sync()
 
 
-_CLASSES = None
+class ShardedTorchMixin:
+  """Device path of a sharded front-end (mixed in before the flavour's front-end class): the
+  same calls as `EnvPoolFrontEnd.reset_torch / recv_torch / step_torch`, over K shards, with
+  nothing crossing PCIe and no host hop for the rows. Results are `ShardedResult`s."""
+
+  @property
+  def all_env_ids(self) -> np.ndarray:
+    if not hasattr(self, "_all_env_ids"):
+      self._all_env_ids = np.arange(self._off, self._off + self._N, dtype=np.int32)
+    return self._all_env_ids
+
+  def _shard_dev(self, r):
+    import torch
+    if not hasattr(self, "_sh_devs"):
+      self._sh_devs = [torch.device("cuda", d) for d in self._devices]
+      self._sh_views = [dict() for _ in range(self._K)]
+    return self._sh_devs[r]
+
+  def _shard_out(self, r, descs, reset):
+    from ..interop import as_torch
+    dev = self._shard_dev(r)
+    cache = self._sh_views[r]  # a shard's ring has ring_depth slots: the same views come round again
+    vals = []
+    for d in descs:
+      if d is None:
+        vals.append(None)
+        continue
+      key = (d[0], tuple(d[1]))
+      t = cache.get(key)
+      if t is None:
+        if len(cache) > 4096:
+          cache.clear()
+        t = cache[key] = as_torch(d, dev)
+      vals.append(t)
+    return self._to(vals, reset, True)
+
+  def _need_device_path(self):
+    if not all(hasattr(s, "_recv_device") for s in self._shards):
+      raise RuntimeError(f"{type(self).__name__}: the shard pools have no device-resident path")
+
+  def _result(self, parts, owners):
+    res = ShardedResult(parts)
+    res.owners = list(owners)
+    self._last_owners = list(owners)
+    return res
+
+  def reset_torch(self):
+    """reset() of every env; per shard the batch as torch tensors aliasing that shard's ring."""
+    self._need_device_path()
+    ids = self.all_env_ids
+    n = self._n_local
+    for r, s in enumerate(self._shards):
+      s._reset(ids[r * n:(r + 1) * n])
+    if self._sync:
+      parts = []
+      for r, s in enumerate(self._shards):
+        parts.append(self._shard_out(r, s._recv_device()[0], True))
+        self._on_part(r, r)
+      return self._result(parts, range(self._K))
+    return self.recv_torch(reset=True)
+
+  def recv_torch(self, reset: bool = False):
+    """The next batch as device views: sync pools - every shard's rows of the outstanding send, in
+    shard order; async pools - K shard batches from whichever shards are ready (`.owners` says
+    which), see ShardedRawPool."""
+    self._need_device_path()
+    if self._sync:
+      if self._pending:
+        n, pos = self._pending.popleft()
+        who = [r for r, p in enumerate(pos) if self._count(p)]
+        if not all(isinstance(pos[r], slice) for r in who):
+          raise RuntimeError("recv_torch of a sharded sync pool needs the sent env ids grouped by shard in ascending shard order")
+      else:
+        who = list(range(self._K))
+      parts = []
+      for i, r in enumerate(who):
+        parts.append(self._shard_out(r, self._shards[r]._recv_device()[0], reset))
+        self._on_part(r, i)
+      return self._result(parts, who)
+    parts = self._gather_parts(lambda r: self._shards[r]._try_recv_device())
+    return self._result([self._shard_out(r, got[0], reset) for r, got in parts], [r for r, _ in parts])
+
+  def _shard_action(self, r, adict, n_rows):
+    """(ptrs, dims, keep) of one shard's action arrays, converted only where dtype / layout / device differ."""
+    import torch
+    keys = self._spec._action_keys
+    if not hasattr(self, "_torch_want"):
+      names = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}
+      self._torch_want = [names[str(spec[0])] for spec in self._spec._action_spec]
+    dev = self._shard_dev(r)
+    ptrs, dims, keep = [], [], []
+    self._converted = getattr(self, "_converted", False)
+    for k, want in zip(keys, self._torch_want):
+      t = adict.get(k)
+      if t is None:  # keys the env never reads may be left out: a stand-in of the right length
+        t = adict["players.env_id"] if k.startswith("players.") else adict["env_id"]
+      if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f'send_torch: action "{k}" must be a CUDA tensor')
+      if t.dtype != want or not t.is_contiguous() or t.device != dev:
+        t = t.to(device=dev, dtype=want).contiguous()
+        self._converted = True  # a snapshot of the caller's tensor: must be taken again next time
+      keep.append(t)
+      ptrs.append(t.data_ptr())
+      dims.append(int(t.shape[0]))
+    return ptrs, dims, keep
+
+  def _split_actions(self, action, env_id, owners):
+    """-> list of (shard, {key: tensor}) for a whole-pool action (env_id None: every env in order)
+    or for per-part actions with their ids and owners (what recv_torch handed out)."""
+    import torch
+    from .pool import _flatten_action
+    keys = self._spec._action_keys
+    out = []
+    if env_id is None:
+      adict = _flatten_action(action) if isinstance(action, dict) else {keys[-1]: action}
+      if not hasattr(self, "_sh_ids"):
+        n = self._n_local
+        self._sh_ids = [torch.from_numpy(self.all_env_ids[r * n:(r + 1) * n].copy()).to(self._shard_dev(r)) for r in range(self._K)]
+      n = self._n_local
+      for r in range(self._K):
+        d = {k: v[r * n:(r + 1) * n] for k, v in adict.items()}
+        d["env_id"] = self._sh_ids[r]
+        d.setdefault("players.env_id", d["env_id"])
+        out.append((r, d))
+      return out
+    if owners is None:
+      owners = self._last_owners
+    if not (isinstance(action, (list, tuple)) and isinstance(env_id, (list, tuple)) and len(action) == len(env_id) == len(owners)):
+      raise RuntimeError("send_torch: pass either a whole-pool action (env_id=None) or per-part lists of actions and env ids "
+                         "with the parts' owners (ShardedResult.owners)")
+    for a, ids, r in zip(action, env_id, owners):
+      d = _flatten_action(a) if isinstance(a, dict) else {keys[-1]: a}
+      d["env_id"] = ids
+      d.setdefault("players.env_id", ids)
+      out.append((int(r), d))
+    return out
+
+  def send_torch(self, action, env_id=None, owners=None):
+    """send() with CUDA tensors: a whole-pool action (sliced per shard; slices on another GPU than
+    their shard's are copied over) or per-part lists as handed out by recv_torch."""
+    import torch
+    self._need_device_path()
+    if not all(hasattr(s, "_send_device") for s in self._shards):
+      raise RuntimeError(f"{type(self).__name__}: actions go through send() as host arrays (the shard pools step on the host)")
+    parts = self._split_actions(action, env_id, owners)
+    staged = [(r,) + self._shard_action(r, d, None) for r, d in parts]
+    for dev in {self._shard_dev(r) for r, *_ in staged}:
+      torch.cuda.current_stream(dev).synchronize()  # the actions were produced on torch's streams
+    self._keep_actions = [k for *_, k in staged]
+    if self._sync:
+      if self._pending:
+        raise RuntimeError("a sharded sync pool takes one send (or reset) per recv")
+      who = [r for r, *_ in staged]
+      if who != sorted(set(who)):
+        raise RuntimeError("a sharded sync pool takes each shard once per send, in ascending shard order")
+      pos = [slice(0, 0)] * self._K
+      at = 0
+      for r, _, dims, _ in staged:
+        pos[r] = slice(at, at + dims[0])
+        at += dims[0]
+      self._pending.append((at, pos))
+    for r, ptrs, dims, _ in staged:
+      self._shards[r]._send_device(ptrs, dims)
+
+  def step_torch(self, action, env_id=None, owners=None):
+    """step() for a policy on the GPUs. A sync pool stepped as a whole rings every shard's resident
+    server first (ep_pool_step_begin) and then waits for each (ep_pool_step_end): the shards step
+    side by side, no kernel launch, no host hop for the rows."""
+    import torch
+    self._need_device_path()
+    if self._sync and env_id is None and not self._pending and all(hasattr(s, "_step_begin") for s in self._shards):
+      # the usual loop passes the same tensors every step: their per-shard slices (pointers, sizes) are kept
+      flat = action.items() if isinstance(action, dict) else ((None, action),)
+      sig = tuple((k, v.data_ptr(), tuple(v.shape), v.dtype, v.device) if isinstance(v, torch.Tensor) else (k, id(v)) for k, v in flat)
+      if getattr(self, "_staged_sig", None) == sig:
+        staged = self._staged
+      else:
+        self._converted = False
+        staged = [(r,) + self._shard_action(r, d, None) for r, d in self._split_actions(action, None, None)]
+        self._staged_sig, self._staged = (None, None) if self._converted else (sig, staged)
+        self._staged_devs = {self._shard_dev(r) for r, *_ in staged}
+      for dev in self._staged_devs:
+        torch.cuda.current_stream(dev).synchronize()
+      self._keep_actions = [k for *_, k in staged]
+      begun = 0
+      try:
+        for r, ptrs, dims, _ in staged:
+          self._shards[r]._step_begin(ptrs, dims)
+          begun += 1
+      except Exception:
+        for r in range(begun):  # the steps that were rung must be ended before anything else can run
+          self._shards[r]._step_end()
+        raise
+      return self._result([self._shard_out(r, self._shards[r]._step_end()[0], False) for r in range(self._K)], range(self._K))
+    self.send_torch(action, env_id, owners)
+    return self.recv_torch()
+
+
+_CLASSES = {}
 
 
 def sharded_dummy_classes():
   """{"dm", "gym", "gymnasium", "raw"} -> pool class of the sharded Dummy-v0 pool; built on the
   first `make(..., num_shards=K)`."""
-  global _CLASSES
-  if _CLASSES is None:
-    _CLASSES = _build_classes()
-  return _CLASSES
+  if "dummy" not in _CLASSES:
+    _CLASSES["dummy"] = _build_dummy_classes()
+  return _CLASSES["dummy"]
 
 
-def _build_classes():
+def sharded_ygopro_classes():
+  """The same for YGOPro-v0: K `ep_ygo_pool`s, shard r's duel engine made by the factory given to
+  `envpool_amd.ygopro.init_module` for that shard's block of global env ids."""
+  if "ygopro" not in _CLASSES:
+    _CLASSES["ygopro"] = _build_ygopro_classes()
+  return _CLASSES["ygopro"]
+
+
+def _flavours(raw_cls, tag):
+  from .pool import DMFrontEnd, EnvPoolFrontEnd, GymFrontEnd, GymnasiumFrontEnd
+
+  def flavour(front, name):
+    meta = type(raw_cls)
+    cls = meta(f"Sharded{tag}{name}EnvPool", (ShardedTorchMixin, front, raw_cls), {})
+
+    def __init__(self, spec, num_shards, devices=None):
+      raw_cls.__init__(self, spec, num_shards, devices)
+      # the front-end's own set-up, minus its super().__init__(spec) hop into the raw class
+      self.spec = spec
+      from .spec import check_unique
+      from .tree import Layout
+      check_unique(type(self).__name__, "state", list(self._state_keys))
+      check_unique(type(self).__name__, "action", list(self._action_keys))
+      self._layout = Layout(self._state_keys)
+      self._dm_layout = Layout(self._state_keys, root="State", merge_info_into_obs=True)
+      self._action_checked = False
+    cls.__init__ = __init__
+    return cls
+
+  return {"dm": flavour(DMFrontEnd, "DM"), "gym": flavour(GymFrontEnd, "Gym"),
+          "gymnasium": flavour(GymnasiumFrontEnd, "Gymnasium"), "raw": flavour(EnvPoolFrontEnd, "Raw")}
+
+
+def _build_dummy_classes():
   from ..dummy.dummy_envpool import _DummyEnvPool, _DummyEnvSpec
-  from .pool import DMFrontEnd, EnvPoolFrontEnd, GymFrontEnd, GymnasiumFrontEnd, make_pool_class
 
   class _ShardedDummyEnvPool(ShardedRawPool):
     _state_keys = _DummyEnvPool._state_keys
@@ -236,26 +608,80 @@ def _build_classes():
         return _DummyEnvPool(_DummyEnvSpec(tuple(vals[k] for k in spec._config_keys)))
 
       ShardedRawPool.__init__(self, cfg["num_envs"], cfg["batch_size"], cfg["max_num_players"], cfg["state_num"],
-                              num_shards, make_shard, devices, cfg["env_id_offset"])
+                              num_shards, make_shard, devices, cfg["env_id_offset"], list(self._state_keys))
 
-  def flavour(front, tag):
-    cls = make_pool_class(f"ShardedDummy{tag}EnvPool", _ShardedDummyEnvPool, front)
-    init = front.__init__
+  return _flavours(_ShardedDummyEnvPool, "Dummy")
 
-    def __init__(self, spec, num_shards, devices=None):
-      _ShardedDummyEnvPool.__init__(self, spec, num_shards, devices)
-      # the front-end's own set-up, minus its super().__init__(spec) hop into the raw class
-      self.spec = spec
-      from .spec import check_unique
-      from .tree import Layout
-      check_unique(type(self).__name__, "state", list(self._state_keys))
-      check_unique(type(self).__name__, "action", list(self._action_keys))
-      self._layout = Layout(self._state_keys)
-      self._dm_layout = Layout(self._state_keys, root="State", merge_info_into_obs=True)
-      self._action_checked = False
-    cls.__init__ = __init__
-    del init
-    return cls
 
-  return {"dm": flavour(DMFrontEnd, "DM"), "gym": flavour(GymFrontEnd, "Gym"),
-          "gymnasium": flavour(GymnasiumFrontEnd, "Gymnasium"), "raw": flavour(EnvPoolFrontEnd, "Raw")}
+def _build_ygopro_classes():
+  from .. import ygopro as Y
+  from ..ygopro.ygopro_envpool import _YGOProEnvSpec
+
+  class _ShardedYGOProEnvPool(ShardedRawPool):
+    _state_keys = Y._YGOProEnvPool._state_keys
+    _action_keys = Y._YGOProEnvPool._action_keys
+
+    def __init__(self, spec, num_shards: int, devices: Optional[Sequence[int]] = None):
+      self._spec = spec
+      cfg = dict(zip(spec._config_keys, spec._config_values))
+      if devices is None:
+        from ..dummy.dummy_envpool import device_count
+        ndev = max(1, device_count())
+        devices = [(Y._MODULE["device_id"] + r) % ndev for r in range(num_shards)]
+      base_off = Y._MODULE["env_id_offset"]
+
+      def make_shard(rank, n, b, off, dev):
+        vals = dict(cfg, num_envs=n, batch_size=b)
+        sub = _YGOProEnvSpec(tuple(vals[k] for k in spec._config_keys))
+        return Y._YGOProEnvPool(sub, device_id=dev, env_id_offset=off, shard=rank)
+
+      ShardedRawPool.__init__(self, cfg["num_envs"], cfg["batch_size"], cfg["max_num_players"], 0, num_shards,
+                              make_shard, devices, base_off, list(self._state_keys))
+      self.last_h_card_ids = self.last_action_mask = None
+      self._aux = []
+
+    def _on_part(self, shard: int, index: int) -> None:
+      # aux:h_card_ids / aux:action_mask (additive keys 17 and 18) of the part just received: the shard
+      # keeps them for ONE batch, so they are picked up part by part
+      if index == 0:
+        self._aux = []
+      sh = self._shards[shard]
+      self._aux.append((sh.last_h_card_ids, sh.last_action_mask, sh.last_env_ids))
+
+    def _recv(self):
+      if self._sync and self._pending and not all(isinstance(p, slice) for p in self._pending[0][1]):
+        raise RuntimeError("a sharded YGOPro sync pool needs the sent env ids grouped by shard in ascending shard order")
+      out = ShardedRawPool._recv(self)
+      if self._aux and all(isinstance(a[0], np.ndarray) for a in self._aux):
+        self.last_h_card_ids = np.concatenate([a[0] for a in self._aux])
+        self.last_action_mask = np.concatenate([a[1] for a in self._aux])
+      return out
+
+    @property
+    def last_env_ids(self) -> np.ndarray:
+      """info:env_id of the batch received last, from host memory, part by part."""
+      return np.concatenate([a[2] for a in self._aux]) if self._aux else np.zeros(0, np.int32)
+
+    @property
+    def last_env_ids_parts(self) -> List[np.ndarray]:
+      """The same, one array per part (what `send(action_i, ids_i)` of an actor loop takes)."""
+      return [a[2] for a in self._aux]
+
+  classes = _flavours(_ShardedYGOProEnvPool, "YGOPro")
+  for cls in classes.values():
+    def recv_torch(self, reset: bool = False, _base=cls.recv_torch):
+      from ..interop import as_torch
+      res = _base(self, reset)
+      # the legal-action mask of every part as a tensor on its shard's GPU (info["action_mask"])
+      masks, hcards = [], []
+      for r, (h, m, _) in zip(res.owners, self._aux):
+        dev = self._shard_dev(r)
+        masks.append(as_torch(m, dev))
+        hcards.append(as_torch(h, dev))
+      self.last_action_mask, self.last_h_card_ids = masks, hcards
+      for part, m in zip(res, masks):
+        if isinstance(part, tuple) and isinstance(part[-1], dict):
+          part[-1]["action_mask"] = m
+      return res
+    cls.recv_torch = recv_torch
+  return classes

@@ -50,10 +50,12 @@ class EnvRegistry:
     shard_devices = kwargs.pop("shard_devices", None)
     spec = self.make_spec(task_id, **kwargs)
     if num_shards > 1:
-      if task_id != "Dummy-v0":
-        raise ValueError(f"num_shards is only implemented for Dummy-v0, not {task_id}")
-      from .python.sharded import sharded_dummy_classes
-      return sharded_dummy_classes()[env_type](spec, num_shards, shard_devices)
+      from .python import sharded
+      if task_id == "Dummy-v0":
+        return sharded.sharded_dummy_classes()[env_type](spec, num_shards, shard_devices)
+      if task_id == "YGOPro-v0":
+        return sharded.sharded_ygopro_classes()[env_type](spec, num_shards, shard_devices)
+      raise ValueError(f"num_shards is implemented for Dummy-v0 and YGOPro-v0, not {task_id}")
     import_path, cls_name = self.envpools[task_id][env_type]
     return getattr(importlib.import_module(import_path), cls_name)(spec)
 

@@ -131,14 +131,31 @@ class _YGOProEnvPool(_YGOProNativePool):
   returns the 16 arrays of `_state_keys` as numpy views of the pinned result block (no copy); the
   additive `aux:h_card_ids` of the last batch is kept in `last_h_card_ids`."""
 
-  def __init__(self, spec):
+  def __init__(self, spec, device_id=None, env_id_offset=None, shard=None):
+    """`device_id`, `env_id_offset`, `shard`: set by the sharded front-end (make(..., num_shards=K)):
+    this pool is shard `shard`, lives on GPU `device_id` and owns the global env ids from
+    `env_id_offset` on. The engine factory is then called as
+    `engine_factory(spec, env_id_offset=..., shard=..., device_id=...)` when it takes those keywords."""
     if _MODULE["engine_factory"] is None:
       raise RuntimeError(
         "YGOPro-v0: the duel engine (ygopro-core, Lua, SQLite card database) is not part of envpool_amd; "
         "call envpool_amd.ygopro.init_module(engine_factory, card_table) first (the reference's init_module "
         "plays the same role), or encode states of your own engine with envpool_amd.ygopro.YGOProEncoder")
     from .. import capi_ygo
-    made = tuple(_MODULE["engine_factory"](spec))
+    factory = _MODULE["engine_factory"]
+    dev = _MODULE["device_id"] if device_id is None else device_id
+    off = _MODULE["env_id_offset"] if env_id_offset is None else env_id_offset
+    if shard is None:
+      made = tuple(factory(spec))
+    else:
+      import inspect
+      try:
+        params = inspect.signature(factory).parameters
+        takes = lambda k: k in params or any(p.kind is p.VAR_KEYWORD for p in params.values())  # noqa: E731
+      except (TypeError, ValueError):
+        takes = lambda k: False  # noqa: E731
+      kw = {k: v for k, v in (("env_id_offset", off), ("shard", shard), ("device_id", dev)) if takes(k)}
+      made = tuple(factory(spec, **kw))
     ctx, reset, step = made[:3]
     engine, keep = capi_ygo.make_engine(ctx, reset, step)
     table = _MODULE["card_table"]
@@ -148,14 +165,30 @@ class _YGOProEnvPool(_YGOProNativePool):
       for i, r in enumerate(rows):
         tab[i] = capi_ygo.CardData(*[int(v) for v in r], 0)
       table = tab
-    super().__init__(spec, (engine.ctx or 0, engine.reset, engine.step), table, _MODULE["device_id"],
-                     _MODULE["env_id_offset"], (keep, made[3:], table))
+    super().__init__(spec, (engine.ctx or 0, engine.reset, engine.step), table, dev, off, (keep, made[3:], table))
     self.last_h_card_ids = self.last_action_mask = None
 
   def _recv(self) -> List[np.ndarray]:
     arrays, _err = self._recv_all()  # (_err: a state the reference throws on; its row is an empty observation)
     self.last_h_card_ids, self.last_action_mask = arrays[16], arrays[17]
     return arrays[:16]
+
+  def _try_recv(self):
+    """Additive: `_recv` that never waits for a batch that is not complete yet (None then)."""
+    got = self._try_recv_all()
+    if got is None:
+      return None
+    arrays, _err = got
+    self.last_h_card_ids, self.last_action_mask = arrays[16], arrays[17]
+    return arrays[:16]
+
+  def _try_recv_device(self):
+    got = self._try_recv_device_all()
+    if got is None:
+      return None
+    descs, rows, prows = got
+    self.last_h_card_ids, self.last_action_mask = descs[16], descs[17]
+    return descs[:16], rows, prows
 
   def _recv_device(self):
     """Additive: the next batch as device views (descriptors for envpool_amd.interop.as_torch): the

@@ -225,6 +225,10 @@ int ep_pool_set_recv_timeout(ep_pool* pool, int64_t milliseconds);
  * thread, state_buffer_queue.h:139-150). */
 int ep_pool_recv_on_stream(ep_pool* pool, void* consumer_stream, ep_batch* out);
 
+/* `n` consecutive ep_pool_recv_on_stream calls in one: the T batches of a rollout handed to a
+ * consumer on the GPU without the host waiting for any of them. */
+int ep_pool_recv_many_on_stream(ep_pool* pool, void* consumer_stream, int32_t n, ep_batch* out);
+
 /* `n` consecutive ep_pool_recv calls in one (the natural companion of
  * ep_pool_rollout). `out` points at n ep_batch structs. */
 int ep_pool_recv_many(ep_pool* pool, int32_t mem, int32_t n, ep_batch* out);

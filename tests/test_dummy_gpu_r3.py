@@ -127,13 +127,16 @@ def test_device_sync_between_steps_stays_cheap():
   g.close()
 
 
-def test_step_begin_end_and_what_is_refused_in_between():
+def test_step_begin_end_and_what_is_refused_in_between(monkeypatch):
   """ep_pool_step_begin rings, ep_pool_step_end waits: two pools stepped at once (what the sharded
   front-end does with one pool per GPU), each against its oracle; between the two halves the pool
-  refuses its other entry points."""
+  refuses its other entry points. (Both pools sit on the one GPU of this box, where the library
+  would keep the resident server out of the way: EP_SERVER_SHARED_DEVICE=1 lets them have it.)"""
   import torch
 
   from envpool_amd import capi
+  monkeypatch.setenv("EP_SERVER_SHARED_DEVICE", "1")
+  monkeypatch.setenv("EP_SERVER_MAX_PER_DEVICE", "4")
   L = capi.lib()
   dev = torch.device("cuda", 0)
   n = 4096

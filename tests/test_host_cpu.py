@@ -393,6 +393,70 @@ def test_sharded_front_end_async_batches(P):
   assert got == want
 
 
+class _PollableShard:
+  """A shard pool that can be polled: batches of `b` rows become complete only when the test says
+  so (a shard whose duel engines are slow)."""
+
+  def __init__(self, rank, n, b, off, dev):
+    self.rank, self.b, self.off = rank, b, off
+    self.ready = 0       # complete batches not yet handed out
+    self.handed = 0
+    self.blocking_recvs = 0
+
+  def _batch(self):
+    ids = (self.off + self.handed * self.b + np.arange(self.b)).astype(np.int32)
+    self.handed += 1
+    z = np.zeros(self.b, np.int32)
+    return [ids, ids, z, z.astype(bool), z.astype(np.float32), z.astype(np.float32), z, z.astype(bool),
+            np.zeros((self.b, 10), np.int32), None, z.astype(bool), z]
+
+  def _try_recv(self):
+    if self.ready == 0:
+      return None
+    self.ready -= 1
+    return self._batch()
+
+  def _recv(self):
+    self.blocking_recvs += 1
+    raise AssertionError("the front-end must not block on one shard")
+
+  def _set_recv_timeout(self, ms):
+    pass
+
+
+def test_sharded_async_recv_takes_whoever_is_ready():
+  """A node-wide async batch is K shard batches from WHICHEVER shards have one complete
+  (state_buffer_queue.h:114-150 hands out the first batch_size arrivals): a shard with nothing
+  ready does not hold the batch up, a shard that is always ready does not crowd the others out,
+  and with nobody ready the call honours the recv timeout instead of sitting on one shard."""
+  from envpool_amd.python.sharded import ShardedRawPool
+  K, n, b = 4, 64, 8
+  sh = ShardedRawPool(K * n, K * b, 1, 10, K, _PollableShard)
+  s = sh.shards
+  # shard 2 is starved, shard 0 has plenty: the batch comes from 0, 1, 3 and 0 again
+  s[0].ready, s[1].ready, s[2].ready, s[3].ready = 5, 1, 0, 1
+  got = sh._recv()
+  assert len(got[0]) == K * b and sorted(sh.last_owners) == [0, 0, 1, 3]
+  owners_of_rows = (np.asarray(got[0]) // n).tolist()
+  assert sorted(set(owners_of_rows)) == [0, 1, 3]
+  # now shard 2 wakes up: it is served although shard 0 still has batches
+  s[2].ready = 2
+  got = sh._recv()
+  assert sorted(sh.last_owners) == [0, 0, 2, 2] or sorted(sh.last_owners) == [0, 2, 0, 2]
+  assert sh.last_owners.count(2) == 2
+  # nobody ready and a bounded timeout: would block, and what was taken is kept for the next call
+  sh._set_recv_timeout(5)
+  s[0].ready, s[1].ready, s[2].ready, s[3].ready = 1, 0, 0, 0   # (shard 0 has 1 left of its 5)
+  with pytest.raises(RuntimeError, match="would block"):
+    sh._recv()
+  s[1].ready = 3
+  got = sh._recv()
+  assert len(got[0]) == K * b and sorted(sh.last_owners) == [0, 1, 1, 1]
+  assert all(x.blocking_recvs == 0 for x in s)
+  # every row handed out exactly once
+  assert s[0].handed == 5 and s[1].handed == 4 and s[2].handed == 2 and s[3].handed == 1
+
+
 def test_headers_are_plain_c_and_cxx(tmp_path):
   """include/*.h is the boundary: it must compile as C99 and as C++11, pedantic, with no warnings,
   and with nothing but the standard headers."""

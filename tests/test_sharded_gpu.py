@@ -248,3 +248,236 @@ def test_two_ranks_ygopro_pools_over_sharded_ids(tmp_path):
      "--master-port", "29539", str(script)], env=env, capture_output=True, text=True, timeout=240)
   assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
   assert out.stdout.count("ok") == 2
+
+
+def _np(t):
+  return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("servers", [True, False])
+def test_sharded_device_path_sync_matches_one_oracle(servers, monkeypatch):
+  """reset_torch / step_torch / send_torch + recv_torch of a sharded sync pool (K = 4 pools on one
+  GPU): the rows never leave the device; per shard the result is that shard's block of ONE big
+  oracle pool, and .cat() is the whole batch in sent (= ascending id) order. servers = True: the
+  shards' resident servers are rung together (ep_pool_step_begin / _end), which pools that share a
+  GPU only do when told to (EP_SERVER_SHARED_DEVICE: one pool per GPU is the deployment the
+  server is for); False: what this one-GPU configuration gets by default, one launch per shard."""
+  import torch
+  if servers:
+    monkeypatch.setenv("EP_SERVER_SHARED_DEVICE", "1")
+    monkeypatch.setenv("EP_SERVER_MAX_PER_DEVICE", "4")
+
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  K, n, seed = 4, 4096, 9
+  G = K * n
+  env = envpool_amd.make("Dummy-v0", "raw", num_envs=G, seed=seed, num_shards=K, shard_devices=[0] * K)
+  one = DummyOracle(num_envs=G, seed=seed)
+  ids = np.arange(G, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+
+  def check(res, want, ctx, reset=False):
+    assert len(res) == K and res.owners == list(range(K))
+    for r, part in enumerate(res):
+      sl = slice(r * n, (r + 1) * n)
+      obs, info = (part[0], part[-1])
+      assert _np(obs["raw"]).tobytes() == want[8][sl].tobytes(), (ctx, r)
+      assert _np(info["env_id"]).tobytes() == want[0][sl].tobytes(), (ctx, r)
+      assert _np(info["elapsed_step"]).tobytes() == want[2][sl].tobytes(), (ctx, r)
+      if not reset:
+        assert _np(part[1]).tobytes() == want[4][sl].tobytes() and _np(part[3]).tobytes() == want[7][sl].tobytes(), (ctx, r)
+        assert _np(part[2]).tobytes() == (want[3] & ~want[7])[sl].tobytes(), (ctx, r)
+    whole = res.cat()
+    assert _np(whole[0]["raw"]).tobytes() == want[8].tobytes() and _np(whole[-1]["players"]["env_id"]).tobytes() == want[1].tobytes(), ctx
+
+  res = env.reset_torch()
+  one._reset(ids)
+  check(res, one._recv(), "reset", reset=True)
+  la = torch.full((G, 6), 1.5, dtype=torch.float64, device=dev)
+  penv = torch.from_numpy(ids).to(dev)
+  act = {"list_action": la, "players.action": penv, "players.id": penv, "players.env_id": penv}
+  rng = np.random.default_rng(0)
+  for t in range(30):
+    pe = ids + (rng.random(G) < 0.1).astype(np.int32)
+    penv.copy_(torch.from_numpy(pe).to(dev))
+    res = env.step_torch(act)
+    one._send(dummy_action(ids, players_env_id=pe))
+    check(res, one._recv(), f"step {t}")
+  # the servers were rung (unless the idle watchdog, which this slow loop invites, moved a shard to the launch path)
+  served = sum(s._server_stats()[2] for s in env.shards)
+  assert served >= K if servers else served == 0
+  # send_torch + recv_torch with per-part lists: one shard only, then two shards
+  for who in ([2], [0, 3]):
+    parts_ids = [torch.from_numpy(ids[r * n:(r + 1) * n].copy()).to(dev) for r in who]
+    parts_act = [{"list_action": la[r * n:(r + 1) * n], "players.action": p, "players.id": p} for r, p in zip(who, parts_ids)]
+    env.send_torch(parts_act, parts_ids, owners=who)
+    res = env.recv_torch()
+    sel = np.concatenate([ids[r * n:(r + 1) * n] for r in who])
+    one._send(dummy_action(sel))
+    want = one._recv()
+    assert res.owners == who
+    got = res.cat()
+    assert _np(got[0]["raw"]).tobytes() == want[8].tobytes() and _np(got[-1]["env_id"]).tobytes() == want[0].tobytes()
+  # and the numpy boundary still works on the same pool afterwards
+  a = dummy_action(rng.permutation(ids))
+  env._send(a); one._send(a)
+  assert_batches_equal(env._recv(), one._recv(), "numpy after torch")
+  env.close()
+
+
+def test_sharded_device_path_async_sets_by_env():
+  """Async sharded pool on the device path: recv_torch hands out K shard batches from whichever
+  shards are ready (`owners`), send_torch routes per-part actions back; per env the rows equal one
+  big pool's (sets keyed by info:env_id)."""
+  import torch
+
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  K, n, b, seed = 4, 1024, 256, 11
+  G = K * n
+  env = envpool_amd.make("Dummy-v0", "raw", num_envs=G, batch_size=K * b, seed=seed, num_shards=K, shard_devices=[0] * K)
+  env._set_recv_timeout(2000)
+  one = DummyOracle(num_envs=G, batch_size=K * b, seed=seed)
+  ids = np.arange(G, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  one._reset(ids)
+  res = env.reset_torch()
+  got, want = {}, {}
+
+  def note(into, env_ids, raw, elapsed):
+    for e, r, s in zip(env_ids.tolist(), raw, elapsed.tolist()):
+      into.setdefault(e, []).append((r.tobytes(), s))
+
+  outstanding = G
+  for it in range(24):
+    assert len(res) == K and all(0 <= r < K for r in res.owners)
+    ids_parts, act_parts = [], []
+    for part in res:
+      e = part[-1]["env_id"]
+      assert e.shape[0] == b
+      note(got, _np(e), _np(part[0]["raw"]), _np(part[-1]["elapsed_step"]))
+      ids_parts.append(e)
+      act_parts.append({"list_action": torch.full((b, 6), 0.5, dtype=torch.float64, device=dev), "players.action": e, "players.id": e})
+    w = one._recv()
+    note(want, w[0], w[8], w[2])
+    # send every received env back; the oracle gets the ids IT handed out
+    env.send_torch(act_parts, ids_parts, owners=res.owners)
+    one._send(dummy_action(w[0], value=0.5))
+    res = env.recv_torch()
+  # both sides handed out every env equally often only over whole rounds; compare the common prefix per env
+  checked = 0
+  for e in range(G):
+    g_rows, w_rows = got.get(e, []), want.get(e, [])
+    m = min(len(g_rows), len(w_rows))
+    assert g_rows[:m] == w_rows[:m], e
+    checked += m
+  assert checked > 0.8 * 24 * K * b
+  env.close()
+
+
+def test_sharded_ygopro_pools_behind_one_front_end():
+  """make("YGOPro-v0", num_envs=K*n, num_shards=K): K ep_ygo_pools (global ids in blocks,
+  ep_ygo_pool_set_env_id_offset), one duel engine per shard from the init_module factory. Sync:
+  rows in sent order; async (config 5's shape scaled down): parts from whoever is ready. Every row
+  against the oracle's encoding of the engine model's state."""
+  import ctypes as C
+
+  import envpool_amd
+  from envpool_amd import capi_ygo, ygopro
+  from oracle import ygo_oracle
+  from tools import ygo_synth
+  K, n = 4, 64
+  G = K * n
+  cfg = capi_ygo.default_config(max_batch=n, ring_depth=0)
+  table = ygo_synth.make_table(1000, seed=0)
+  engines, models = {}, {}
+
+  def factory(spec, env_id_offset=0, shard=0):
+    eng = ygo_synth.SynthEngine(cfg, table, n, seed=20 + shard)
+    eng.set_env_id_offset(env_id_offset)
+    engines[shard] = eng
+    models[shard] = ygo_synth.EnginePoolModel(cfg, table, n, seed=20 + shard)
+    return eng.ctx, eng.reset_addr, eng.step_addr, eng
+
+  def expect(env_ids, actions):
+    raws = []
+    for e, a in zip(env_ids, actions):
+      r, loc = divmod(int(e), n)
+      raw = models[r].advance(loc) if a is None else models[r].advance(loc, int(a))
+      raw.env_id = int(e)
+      raws.append(raw)
+    arr = (capi_ygo.RawState * len(raws))()
+    for i, r in enumerate(raws):
+      C.memmove(C.byref(arr[i]), C.byref(r), C.sizeof(capi_ygo.RawState))
+    return ygo_oracle.write_batch(cfg, table, arr, len(raws))
+
+  ygopro.init_module(factory, table)
+  try:
+    # ---- sync ----
+    env = envpool_amd.make("YGOPro-v0", "raw", num_envs=G, num_threads=2, num_shards=K, shard_devices=[0] * K)
+    env._set_recv_timeout(30000)
+    ids = np.arange(G, dtype=np.int32)
+    rng = np.random.default_rng(2)
+    env._reset(ids)
+    out = env._recv()
+    want, status = expect(ids, [None] * G)
+    ok = np.flatnonzero(np.asarray(status) == 0)
+    for k in range(16):
+      assert np.asarray(out[k])[ok].tobytes() == np.asarray(want[k])[ok].tobytes(), ("reset", k)
+    assert env.last_env_ids.tolist() == ids.tolist() and env.last_action_mask.shape == (G, 16)
+    for it in range(6):
+      sel = ids if it % 2 == 0 else np.sort(rng.choice(G, size=int(rng.integers(1, G)), replace=False)).astype(np.int32)
+      act = rng.integers(0, 16, size=sel.size).astype(np.int32)
+      env._send([sel, sel, act])
+      out = env._recv()
+      assert out[0].tolist() == sel.tolist()
+      want, status = expect(sel, act)
+      ok = np.flatnonzero(np.asarray(status) == 0)
+      for k in range(16):
+        assert np.asarray(out[k])[ok].tobytes() == np.asarray(want[k])[ok].tobytes(), (it, k)
+      assert np.asarray(env.last_h_card_ids)[ok].tobytes() == np.asarray(want[16])[ok].tobytes()
+    # the user-facing API and the device path: torch views per shard, mask included
+    obs, rew, term, trunc, info = env.step(np.ones(G, dtype=np.int32))
+    assert obs["cards_"].shape == (G, 150, 39) and info["env_id"].tolist() == ids.tolist()
+    expect(ids, np.ones(G, np.int32))
+    env.send(np.full(G, 2, np.int32))
+    res = env.recv_torch()
+    expect(ids, np.full(G, 2, np.int32))
+    assert len(res) == K and all(p[0]["cards_"].is_cuda and tuple(p[0]["cards_"].shape) == (n, 150, 39) for p in res)
+    assert all(tuple(p[-1]["action_mask"].shape) == (n, 16) for p in res)
+    assert np.concatenate([p[-1]["env_id"].cpu().numpy() for p in res]).tolist() == ids.tolist()
+    env.close()
+    for e in engines.values():
+      e.close()
+    engines.clear(); models.clear()
+
+    # ---- async: 4 x 64 envs, node-wide batches of 128 = 4 shard batches of 32 ----
+    env = envpool_amd.make("YGOPro-v0", "raw", num_envs=G, batch_size=G // 2, num_threads=2, num_shards=K, shard_devices=[0] * K)
+    env._set_recv_timeout(30000)
+    env._reset(ids)
+    pending = {}
+    want0, status0 = expect(ids, [None] * G)
+    for j, e in enumerate(ids.tolist()):
+      pending[e] = (tuple(np.asarray(want0[k][j]).tobytes() for k in range(16)), int(status0[j]))
+    checked = 0
+    for it in range(10):
+      out = env._recv()
+      got_ids = np.asarray(out[0])
+      assert got_ids.shape[0] == G // 2 and len(set(got_ids.tolist())) == G // 2
+      assert env.last_env_ids.tolist() == got_ids.tolist()
+      for j, e in enumerate(got_ids.tolist()):
+        row, st = pending.pop(e)
+        if st == 0:
+          assert tuple(np.asarray(out[k][j]).tobytes() for k in range(16)) == row, (it, j, e)
+          checked += 1
+      act = rng.integers(0, 16, size=got_ids.size).astype(np.int32)
+      env._send([got_ids, got_ids, act])
+      w, stt = expect(got_ids, act)
+      for j, e in enumerate(got_ids.tolist()):
+        pending[e] = (tuple(np.asarray(w[k][j]).tobytes() for k in range(16)), int(stt[j]))
+    assert checked > 0.85 * 10 * (G // 2)
+    env.close()
+  finally:
+    ygopro.init_module(None, None)
+    for e in engines.values():
+      e.close()

@@ -29,19 +29,7 @@ def run(n_big=65536, n_cfg3=1024, iters=200, cpu_seconds=0.0, device=0):
   recs, est = capi_ygo.emit_records(cfg, sb.raw, n_gen)
   emit_s = time.perf_counter() - t0
   stride = recs.shape[1]
-  # algorithmic bytes per record: what the kernel must read (header + history + listed cards +
-  # options actually present) and write (every output key)
-  hdr = recs[:, :64]
-  loc = hdr[:, 48:62].reshape(-1, 2, 7).astype(np.int64)
-  revealed_any = hdr[:, 5].astype(bool)
-  listed = loc[:, 0, :].sum(1) + loc[:, 1, 2:6].sum(1) + np.where(revealed_any, loc[:, 1, 1], 0)
-  n_opt = np.minimum(hdr[:, 3].astype(np.int64), cfg.max_options)
-  nf = 9 + 2 * cfg.max_multi_select
-  read_b = 64 + cfg.n_history_actions * nf + listed * 16 + n_opt * (12 + 4 * cfg.max_multi_select)
-  read_b = np.where(hdr[:, 3] == 0, 64, read_b)
-  write_b = 2 * cfg.max_cards * 39 + 8 + cfg.max_options * nf + cfg.n_history_actions * nf + 4 * 4 + (4 + 4 + 4 + 1 + 4 + 4 + 4 + 1) \
-      + cfg.max_options * cfg.max_multi_select * 2 + cfg.max_options  # (+ aux:h_card_ids, aux:action_mask)
-  alg_per_rec = float(read_b.mean() + write_b)
+  alg_per_rec = alg_bytes_per_record(cfg, recs)
 
   enc = capi_ygo.YgoEncoderC(cfg, table, len(table))
   h = enc.handle
@@ -446,6 +434,23 @@ def run_config3_packed(device=0, n_envs=1024, steps_per_env=100, threads=4):
   return out
 
 
+def alg_bytes_per_record(cfg, recs):
+  """Algorithmic bytes per record: what the kernel must read (header + history + listed cards +
+  options actually present) and write (every output key), averaged over `recs`."""
+  import numpy as np
+  hdr = recs[:, :64]
+  loc = hdr[:, 48:62].reshape(-1, 2, 7).astype(np.int64)
+  revealed_any = hdr[:, 5].astype(bool)
+  listed = loc[:, 0, :].sum(1) + loc[:, 1, 2:6].sum(1) + np.where(revealed_any, loc[:, 1, 1], 0)
+  n_opt = np.minimum(hdr[:, 3].astype(np.int64), cfg.max_options)
+  nf = 9 + 2 * cfg.max_multi_select
+  read_b = 64 + cfg.n_history_actions * nf + listed * 16 + n_opt * (12 + 4 * cfg.max_multi_select)
+  read_b = np.where(hdr[:, 3] == 0, 64, read_b)
+  write_b = 2 * cfg.max_cards * 39 + 8 + cfg.max_options * nf + cfg.n_history_actions * nf + 4 * 4 + (4 + 4 + 4 + 1 + 4 + 4 + 4 + 1) \
+      + cfg.max_options * cfg.max_multi_select * 2 + cfg.max_options  # (+ aux:h_card_ids, aux:action_mask)
+  return float(read_b.mean() + write_b)
+
+
 def run_shard(device, barrier, n_big=65536, n_step=512, iters=200, steps=400):
   """One rank's share of a multi-GPU run (envs shard by env_id, no exchange): the device-resident
   large batch and the per-GPU shape of BASELINE config 5 (512 host records per step through the
@@ -480,6 +485,19 @@ def run_shard(device, barrier, n_big=65536, n_step=512, iters=200, steps=400):
   assert L.ep_ygo_collect(enc.handle, capi.EP_MEM_DEVICE, C.byref(b)) in ok
   barrier()
   t_big = time.perf_counter() - t0
+  # this rank's kernel duration (HIP events, a pass of its own outside the timed region): the roofline figure
+  tot, cnt = C.c_double(), C.c_int64()
+  L.ep_ygo_set_timing(enc.handle, 1)
+  L.ep_ygo_kernel_time_us(enc.handle, C.byref(tot), C.byref(cnt), 1)
+  assert L.ep_ygo_submit_device(enc.handle, big.data_ptr(), n_big) == 0
+  for _ in range(99):
+    assert L.ep_ygo_submit_device(enc.handle, big.data_ptr(), n_big) == 0
+    assert L.ep_ygo_collect(enc.handle, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  assert L.ep_ygo_collect(enc.handle, capi.EP_MEM_DEVICE, C.byref(b)) in ok
+  L.ep_ygo_kernel_time_us(enc.handle, C.byref(tot), C.byref(cnt), 1)
+  L.ep_ygo_set_timing(enc.handle, 0)
+  big_kernel_us = tot.value / max(1, cnt.value)
+  alg_per_rec = alg_bytes_per_record(cfg, recs)
   enc.close()
   del big
 
@@ -512,7 +530,8 @@ def run_shard(device, barrier, n_big=65536, n_step=512, iters=200, steps=400):
   # config 5 as a whole on this rank: 4 stand-in duel threads feeding the arrival-ordered ring
   ring = run_config5(device, threads_list=(4,), steps_per_env=20)["by_threads"]["4"]
   return {"large_wall_s": t_big, "large_records": n_big * iters, "pipeline_wall_s": t_step, "pipeline_records": n_step * steps,
-          "records_per_launch": n_big, "records_per_step": n_step, "ring_4_threads": ring}
+          "records_per_launch": n_big, "records_per_step": n_step, "ring_4_threads": ring,
+          "large_kernel_us": big_kernel_us, "alg_bytes_per_record": alg_per_rec}
 
 if __name__ == "__main__":
   print(json.dumps(run(cpu_seconds=float(os.environ.get("EP_YGO_CPU_SECONDS", "3")))))

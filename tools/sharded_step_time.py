@@ -1,10 +1,11 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np
 import envpool_amd
 def med(ts):
     ts = sorted(ts); return ts[len(ts)//2]*1e6
-for n, k in ((4096, 1), (4096, 4), (65536, 1), (65536, 4), (65536, 8)):
+NUMPY = os.environ.get('ONLY_TORCH') != '1'
+for n, k in ((4096, 1), (4096, 4), (65536, 1), (65536, 4), (65536, 8)) if NUMPY else ():
     env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42, num_shards=k) if k > 1 else envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42)
     env.reset()
     act = {"list_action": np.full((n, 6), 1.5), "players.action": np.zeros(n, np.int32), "players.id": np.zeros(n, np.int32)}
@@ -14,7 +15,7 @@ for n, k in ((4096, 1), (4096, 4), (65536, 1), (65536, 4), (65536, 8)):
     print(f"n={n} shards={k}: env.step {med(ts[30:]):8.1f} us", flush=True)
 
 # async: config 5's shape in one process (8192 envs, batches of 4096, 8 shards), recv + send
-for n, b, k in ((8192, 4096, 1), (8192, 4096, 8)):
+for n, b, k in ((8192, 4096, 1), (8192, 4096, 8)) if NUMPY else ():
     kw = dict(num_shards=k) if k > 1 else {}
     env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, batch_size=b, seed=42, **kw)
     env.async_reset()
@@ -26,3 +27,39 @@ for n, b, k in ((8192, 4096, 1), (8192, 4096, 8)):
         env.send(act, info["env_id"])
         ts.append(time.perf_counter() - t0)
     print(f"async n={n} batch={b} shards={k}: recv + send {med(ts[50:]):8.1f} us per batch", flush=True)
+
+# the device path (round 3): CUDA tensors in, per-shard views of the rings out, nothing crosses PCIe;
+# a whole-pool step rings every shard's resident server and then waits for each
+import torch
+for n, k in ((65536, 1), (65536, 4), (65536, 8), (524288, 8)) if os.environ.get('ONLY_K4') != '1' else ((65536, 4),):
+    kw = dict(num_shards=k, shard_devices=[0] * k) if k > 1 else {}
+    env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42, **kw)
+    env.reset_torch()
+    la = torch.full((n, 6), 1.5, dtype=torch.float64, device="cuda")
+    ts, tc = [], []
+    for i in range(1200):
+        t0 = time.perf_counter(); res = env.step_torch({"list_action": la}); ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    line = f"n={n} shards={k}: env.step_torch {med(ts[200:]):8.1f} us"
+    if k > 1:
+        for i in range(200):
+            res = env.step_torch({"list_action": la})
+            t0 = time.perf_counter(); whole = res.cat(); torch.cuda.current_stream().synchronize(); tc.append(time.perf_counter() - t0)
+        line += f"   (+ .cat() of the {k} parts into one tensor per key, synchronised: {med(tc[50:]):6.1f} us)"
+        line += f"   servers (launches, idle stops, steps served): {[s._server_stats()[:3] for s in env.shards]}"
+    print(line, flush=True)
+    env.close()
+
+if os.environ.get("PROFILE_K4") == "1":
+    import cProfile, pstats
+    env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=65536, seed=42, num_shards=4, shard_devices=[0] * 4)
+    env.reset_torch()
+    la = torch.full((65536, 6), 1.5, dtype=torch.float64, device="cuda")
+    for i in range(300):
+        env.step_torch({"list_action": la})
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(1000):
+        env.step_torch({"list_action": la})
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
