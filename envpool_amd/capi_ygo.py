@@ -35,6 +35,13 @@ class CardData(C.Structure):
               ("pad", C.c_uint16)]
 
 
+class CoreConstants(C.Structure):
+  """ep_ygo_core_constants (include/envpool_amd_ygo_consts.h)."""
+  _fields_ = [("location", C.c_int32 * 8), ("pos", C.c_int32 * 8), ("type", C.c_uint32 * 25), ("attribute", C.c_uint32 * 7),
+              ("race", C.c_uint32 * 26), ("phase", C.c_int32 * 10), ("msg", C.c_int32 * 14), ("query_equip_card", C.c_uint32),
+              ("len_empty", C.c_int32)]
+
+
 class RawState(C.Structure):
   _fields_ = [
     ("to_play", C.c_int32), ("turn_player", C.c_int32), ("msg", C.c_int32), ("current_phase", C.c_int32),
@@ -56,6 +63,7 @@ SYMBOLS = [
   "ep_ygo_commit_slot_packed", "ep_ygo_commit_slot_rows", "ep_ygo_emit_records_packed",
   "ep_ygo_pool_create", "ep_ygo_pool_destroy", "ep_ygo_pool_send", "ep_ygo_pool_reset", "ep_ygo_pool_recv",
   "ep_ygo_last_env_ids", "ep_ygo_pool_last_env_ids", "ep_ygo_pool_set_recv_timeout", "ep_ygo_pool_encoder", "ep_ygo_pool_num_threads", "ep_ygo_pool_set_env_id_offset",
+  "ep_ygo_default_constants", "ep_ygo_check_constants",
 ]
 
 # the duel-engine callbacks of ep_ygo_pool_create
@@ -126,6 +134,9 @@ def lib():
     L.ep_ygo_last_env_ids.argtypes = [vp, vp, vp]
     L.ep_ygo_pool_set_env_id_offset.argtypes = [vp, i32]
     L.ep_ygo_history_push.argtypes = [C.POINTER(YgoConfig), vp, C.POINTER(i32), i32, C.c_char_p, vp, i32]
+    L.ep_ygo_default_constants.argtypes = [C.POINTER(CoreConstants)]
+    L.ep_ygo_default_constants.restype = None
+    L.ep_ygo_check_constants.argtypes = [C.POINTER(CoreConstants)]
     _bound = L
   return _bound
 

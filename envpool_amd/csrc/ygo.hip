@@ -393,7 +393,7 @@ int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t
       // attribute2id (ygopro.h:563-571): {0,1,2,4,8,16,32,64} -> 0..7
       h.attr_id = 0xff;
       if (c.attribute == 0) h.attr_id = 0;
-      else if ((c.attribute & (c.attribute - 1)) == 0 && c.attribute <= 0x40) h.attr_id = (uint8_t)(__builtin_ctz(c.attribute) + 1);
+      else if ((c.attribute & (c.attribute - 1)) == 0 && c.attribute <= EP_YGO_ATTRIBUTE_DEVINE) h.attr_id = (uint8_t)(__builtin_ctz(c.attribute) + 1);
       // race2id (:575-605): {0, bit0..bit25} -> 0..26
       h.race_id = 0xff;
       if (c.race == 0) h.race_id = 0;
@@ -583,6 +583,20 @@ int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int
   s.busy = true;
   e->submit_idx++;
   *completed = 1;
+  return EP_OK;
+}
+
+// Gives up the batch being committed in parts (a part's launch failed): waits for the parts that
+// did go out and forgets them, so that the slot starts clean for the next batch.
+int ep_ygo_abort_slot(ep_ygo_encoder* e) {
+  if (!e) return fail(EP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  Slot& s = e->slots[(size_t)(e->submit_idx % e->slots.size())];
+  if (s.rows_launched == 0) return EP_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipStreamSynchronize(e->copy_stream));
+  s.rows_launched = 0;
   return EP_OK;
 }
 
@@ -1006,14 +1020,92 @@ int ep_ygo_kernel_time_us(ep_ygo_encoder* e, double* total_us, int64_t* launches
 
 }  // extern "C"
 
+// ---- ygopro-core constants (include/envpool_amd_ygo_consts.h) ----------------------------------
+extern "C" {
+
+void ep_ygo_default_constants(ep_ygo_core_constants* o) {
+  if (!o) return;
+  const int32_t loc[8] = {EP_YGO_LOCATION_DECK, EP_YGO_LOCATION_HAND, EP_YGO_LOCATION_MZONE, EP_YGO_LOCATION_SZONE,
+                          EP_YGO_LOCATION_GRAVE, EP_YGO_LOCATION_REMOVED, EP_YGO_LOCATION_EXTRA, EP_YGO_LOCATION_OVERLAY};
+  const int32_t pos[8] = {EP_YGO_POS_FACEUP_ATTACK, EP_YGO_POS_FACEDOWN_ATTACK, EP_YGO_POS_FACEUP_DEFENSE, EP_YGO_POS_FACEDOWN_DEFENSE,
+                          EP_YGO_POS_FACEUP, EP_YGO_POS_FACEDOWN, EP_YGO_POS_ATTACK, EP_YGO_POS_DEFENSE};
+  const uint32_t type[EP_YGO_NUM_TYPES] = {
+      EP_YGO_TYPE_MONSTER, EP_YGO_TYPE_SPELL, EP_YGO_TYPE_TRAP, EP_YGO_TYPE_NORMAL, EP_YGO_TYPE_EFFECT, EP_YGO_TYPE_FUSION, EP_YGO_TYPE_RITUAL,
+      EP_YGO_TYPE_TRAPMONSTER, EP_YGO_TYPE_SPIRIT, EP_YGO_TYPE_UNION, EP_YGO_TYPE_DUAL, EP_YGO_TYPE_TUNER, EP_YGO_TYPE_SYNCHRO, EP_YGO_TYPE_TOKEN,
+      EP_YGO_TYPE_QUICKPLAY, EP_YGO_TYPE_CONTINUOUS, EP_YGO_TYPE_EQUIP, EP_YGO_TYPE_FIELD, EP_YGO_TYPE_COUNTER, EP_YGO_TYPE_FLIP, EP_YGO_TYPE_TOON,
+      EP_YGO_TYPE_XYZ, EP_YGO_TYPE_PENDULUM, EP_YGO_TYPE_SPSUMMON, EP_YGO_TYPE_LINK};
+  const uint32_t attr[EP_YGO_NUM_ATTRIBUTES] = {EP_YGO_ATTRIBUTE_EARTH, EP_YGO_ATTRIBUTE_WATER, EP_YGO_ATTRIBUTE_FIRE, EP_YGO_ATTRIBUTE_WIND,
+                                                EP_YGO_ATTRIBUTE_LIGHT, EP_YGO_ATTRIBUTE_DARK, EP_YGO_ATTRIBUTE_DEVINE};
+  const int32_t phase[EP_YGO_NUM_PHASES] = {EP_YGO_PHASE_DRAW, EP_YGO_PHASE_STANDBY, EP_YGO_PHASE_MAIN1, EP_YGO_PHASE_BATTLE_START,
+                                            EP_YGO_PHASE_BATTLE_STEP, EP_YGO_PHASE_DAMAGE, EP_YGO_PHASE_DAMAGE_CAL, EP_YGO_PHASE_BATTLE,
+                                            EP_YGO_PHASE_MAIN2, EP_YGO_PHASE_END};
+  const int32_t msg[EP_YGO_NUM_MSGS] = {
+      EP_YGO_MSG_SELECT_IDLECMD, EP_YGO_MSG_SELECT_CHAIN, EP_YGO_MSG_SELECT_CARD, EP_YGO_MSG_SELECT_TRIBUTE, EP_YGO_MSG_SELECT_POSITION,
+      EP_YGO_MSG_SELECT_EFFECTYN, EP_YGO_MSG_SELECT_YESNO, EP_YGO_MSG_SELECT_BATTLECMD, EP_YGO_MSG_SELECT_UNSELECT_CARD,
+      EP_YGO_MSG_SELECT_OPTION, EP_YGO_MSG_SELECT_PLACE, EP_YGO_MSG_SELECT_SUM, EP_YGO_MSG_SELECT_DISFIELD, EP_YGO_MSG_ANNOUNCE_ATTRIB};
+  memcpy(o->location, loc, sizeof(loc));
+  memcpy(o->pos, pos, sizeof(pos));
+  memcpy(o->type, type, sizeof(type));
+  memcpy(o->attribute, attr, sizeof(attr));
+  for (int i = 0; i < EP_YGO_NUM_RACES; ++i) o->race[i] = EP_YGO_RACE(i);
+  memcpy(o->phase, phase, sizeof(phase));
+  memcpy(o->msg, msg, sizeof(msg));
+  o->query_equip_card = EP_YGO_QUERY_EQUIP_CARD;
+  o->len_empty = EP_YGO_LEN_EMPTY;
+}
+
+int ep_ygo_check_constants(const ep_ygo_core_constants* t) {
+  if (!t) return fail(EP_ERR_INVALID, "null argument");
+  ep_ygo_core_constants m;
+  ep_ygo_default_constants(&m);
+  static const char* const kLoc[8] = {"LOCATION_DECK", "LOCATION_HAND", "LOCATION_MZONE", "LOCATION_SZONE", "LOCATION_GRAVE",
+                                      "LOCATION_REMOVED", "LOCATION_EXTRA", "LOCATION_OVERLAY"};
+  static const char* const kPos[8] = {"POS_FACEUP_ATTACK", "POS_FACEDOWN_ATTACK", "POS_FACEUP_DEFENSE", "POS_FACEDOWN_DEFENSE", "POS_FACEUP",
+                                      "POS_FACEDOWN", "POS_ATTACK", "POS_DEFENSE"};
+  static const char* const kType[EP_YGO_NUM_TYPES] = {
+      "TYPE_MONSTER", "TYPE_SPELL", "TYPE_TRAP", "TYPE_NORMAL", "TYPE_EFFECT", "TYPE_FUSION", "TYPE_RITUAL", "TYPE_TRAPMONSTER", "TYPE_SPIRIT",
+      "TYPE_UNION", "TYPE_DUAL", "TYPE_TUNER", "TYPE_SYNCHRO", "TYPE_TOKEN", "TYPE_QUICKPLAY", "TYPE_CONTINUOUS", "TYPE_EQUIP", "TYPE_FIELD",
+      "TYPE_COUNTER", "TYPE_FLIP", "TYPE_TOON", "TYPE_XYZ", "TYPE_PENDULUM", "TYPE_SPSUMMON", "TYPE_LINK"};
+  static const char* const kAttr[EP_YGO_NUM_ATTRIBUTES] = {"ATTRIBUTE_EARTH", "ATTRIBUTE_WATER", "ATTRIBUTE_FIRE", "ATTRIBUTE_WIND",
+                                                           "ATTRIBUTE_LIGHT", "ATTRIBUTE_DARK", "ATTRIBUTE_DEVINE"};
+  static const char* const kRace[EP_YGO_NUM_RACES] = {
+      "RACE_WARRIOR", "RACE_SPELLCASTER", "RACE_FAIRY", "RACE_FIEND", "RACE_ZOMBIE", "RACE_MACHINE", "RACE_AQUA", "RACE_PYRO", "RACE_ROCK",
+      "RACE_WINDBEAST", "RACE_PLANT", "RACE_INSECT", "RACE_THUNDER", "RACE_DRAGON", "RACE_BEAST", "RACE_BEASTWARRIOR", "RACE_DINOSAUR",
+      "RACE_FISH", "RACE_SEASERPENT", "RACE_REPTILE", "RACE_PSYCHO", "RACE_DEVINE", "RACE_CREATORGOD", "RACE_WYRM", "RACE_CYBERSE", "RACE_ILLUSION"};
+  static const char* const kPhase[EP_YGO_NUM_PHASES] = {"PHASE_DRAW", "PHASE_STANDBY", "PHASE_MAIN1", "PHASE_BATTLE_START", "PHASE_BATTLE_STEP",
+                                                        "PHASE_DAMAGE", "PHASE_DAMAGE_CAL", "PHASE_BATTLE", "PHASE_MAIN2", "PHASE_END"};
+  static const char* const kMsg[EP_YGO_NUM_MSGS] = {
+      "MSG_SELECT_IDLECMD", "MSG_SELECT_CHAIN", "MSG_SELECT_CARD", "MSG_SELECT_TRIBUTE", "MSG_SELECT_POSITION", "MSG_SELECT_EFFECTYN",
+      "MSG_SELECT_YESNO", "MSG_SELECT_BATTLECMD", "MSG_SELECT_UNSELECT_CARD", "MSG_SELECT_OPTION", "MSG_SELECT_PLACE", "MSG_SELECT_SUM",
+      "MSG_SELECT_DISFIELD", "MSG_ANNOUNCE_ATTRIB"};
+  auto differ = [](const char* name, long long mine, long long theirs) {
+    return fail(EP_ERR_INVALID,
+                "ygopro-core constant %s: this library was built for 0x%llx (%lld), the caller's common.h has 0x%llx (%lld) - "
+                "observations would carry wrong ids; rebuild with include/envpool_amd_ygo_consts.h corrected",
+                name, mine, mine, theirs, theirs);
+  };
+  for (int i = 0; i < 8; ++i) if (m.location[i] != t->location[i]) return differ(kLoc[i], m.location[i], t->location[i]);
+  for (int i = 0; i < 8; ++i) if (m.pos[i] != t->pos[i]) return differ(kPos[i], m.pos[i], t->pos[i]);
+  for (int i = 0; i < EP_YGO_NUM_TYPES; ++i) if (m.type[i] != t->type[i]) return differ(kType[i], m.type[i], t->type[i]);
+  for (int i = 0; i < EP_YGO_NUM_ATTRIBUTES; ++i) if (m.attribute[i] != t->attribute[i]) return differ(kAttr[i], m.attribute[i], t->attribute[i]);
+  for (int i = 0; i < EP_YGO_NUM_RACES; ++i) if (m.race[i] != t->race[i]) return differ(kRace[i], m.race[i], t->race[i]);
+  for (int i = 0; i < EP_YGO_NUM_PHASES; ++i) if (m.phase[i] != t->phase[i]) return differ(kPhase[i], m.phase[i], t->phase[i]);
+  for (int i = 0; i < EP_YGO_NUM_MSGS; ++i) if (m.msg[i] != t->msg[i]) return differ(kMsg[i], m.msg[i], t->msg[i]);
+  if (m.query_equip_card != t->query_equip_card) return differ("QUERY_EQUIP_CARD", m.query_equip_card, t->query_equip_card);
+  if (m.len_empty != t->len_empty) return differ("LEN_EMPTY", m.len_empty, t->len_empty);
+  return EP_OK;
+}
+
+}  // extern "C"
+
 // =========================================================================================
 // Host adapter: reference data forms -> POD record. No GPU involved.
 // =========================================================================================
 namespace {
 
-constexpr uint32_t kQueryEquipCard = 0x4000;  // ygopro-core common.h QUERY_EQUIP_CARD
-constexpr uint32_t kLenEmpty = 4;             // ygopro-core LEN_EMPTY
-constexpr uint8_t kLocationOverlay = 0x80;
+constexpr uint32_t kQueryEquipCard = EP_YGO_QUERY_EQUIP_CARD;  // (include/envpool_amd_ygo_consts.h)
+constexpr uint32_t kLenEmpty = EP_YGO_LEN_EMPTY;
+constexpr uint8_t kLocationOverlay = EP_YGO_LOCATION_OVERLAY;
 
 inline uint32_t ld32(const uint8_t* p) {
   uint32_t v;
@@ -1098,15 +1190,15 @@ bool spec_key(std::string_view s, uint32_t* key) {
   if (i >= s.size()) return false;
   uint32_t loc;
   switch (s[i]) {
-    case 'h': loc = 0x02; ++i; break;
-    case 'm': loc = 0x04; ++i; break;
-    case 's': loc = 0x08; ++i; break;
-    case 'g': loc = 0x10; ++i; break;
-    case 'r': loc = 0x20; ++i; break;
-    case 'x': loc = 0x40; ++i; break;
+    case 'h': loc = EP_YGO_LOCATION_HAND; ++i; break;
+    case 'm': loc = EP_YGO_LOCATION_MZONE; ++i; break;
+    case 's': loc = EP_YGO_LOCATION_SZONE; ++i; break;
+    case 'g': loc = EP_YGO_LOCATION_GRAVE; ++i; break;
+    case 'r': loc = EP_YGO_LOCATION_REMOVED; ++i; break;
+    case 'x': loc = EP_YGO_LOCATION_EXTRA; ++i; break;
     default:
       if (!isdigit((unsigned char)s[i])) return false;
-      loc = 0x01;
+      loc = EP_YGO_LOCATION_DECK;
   }
   size_t j = i;
   uint32_t v = 0;
@@ -1138,7 +1230,10 @@ int place_id(std::string_view s) {  // cmd_place2id (:680-686)
 }
 
 int msg_id(int msg) {  // msg2id (:660-669)
-  static const int msgs[14] = {11, 16, 15, 20, 19, 12, 13, 10, 26, 14, 18, 23, 24, 141};
+  static const int msgs[EP_YGO_NUM_MSGS] = {
+      EP_YGO_MSG_SELECT_IDLECMD, EP_YGO_MSG_SELECT_CHAIN, EP_YGO_MSG_SELECT_CARD, EP_YGO_MSG_SELECT_TRIBUTE, EP_YGO_MSG_SELECT_POSITION,
+      EP_YGO_MSG_SELECT_EFFECTYN, EP_YGO_MSG_SELECT_YESNO, EP_YGO_MSG_SELECT_BATTLECMD, EP_YGO_MSG_SELECT_UNSELECT_CARD,
+      EP_YGO_MSG_SELECT_OPTION, EP_YGO_MSG_SELECT_PLACE, EP_YGO_MSG_SELECT_SUM, EP_YGO_MSG_SELECT_DISFIELD, EP_YGO_MSG_ANNOUNCE_ATTRIB};
   for (int i = 0; i < 14; ++i)
     if (msgs[i] == msg) return i + 1;
   return -1;
@@ -1189,7 +1284,7 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
   };
   int rc;
   switch (msg) {
-    case 11: {  // MSG_SELECT_IDLECMD
+    case EP_YGO_MSG_SELECT_IDLECMD: {
       if (option == "b" || option == "e") {
         feats[F_PHASE] = (uint8_t)list_id("bme", option[0]);
       } else {
@@ -1203,7 +1298,7 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
       }
       break;
     }
-    case 16: {  // MSG_SELECT_CHAIN
+    case EP_YGO_MSG_SELECT_CHAIN: {
       if (option[0] == 'c') {
         feats[F_CANCEL] = 1;
       } else {
@@ -1214,7 +1309,7 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
       }
       break;
     }
-    case 15: case 20: case 23: {  // CARD / TRIBUTE / SUM: space separated specs
+    case EP_YGO_MSG_SELECT_CARD: case EP_YGO_MSG_SELECT_TRIBUTE: case EP_YGO_MSG_SELECT_SUM: {  // space separated specs
       size_t start = 0;
       while (start < option.size()) {
         const size_t idx = option.find(' ', start);
@@ -1224,30 +1319,30 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
       }
       break;
     }
-    case 26: {  // MSG_SELECT_UNSELECT_CARD
+    case EP_YGO_MSG_SELECT_UNSELECT_CARD: {
       if (option[0] == 'f') feats[F_CANCEL] = 2;
       else specs->push_back(option);
       break;
     }
-    case 19: {  // MSG_SELECT_POSITION
+    case EP_YGO_MSG_SELECT_POSITION: {
       const int sh = option[0] - '1';
       const int pid = (sh >= 0 && sh < 8) ? pos_id_host(1 << sh) : -1;
       if ((rc = need(pid, "position"))) return rc;
       feats[F_POSITION] = (uint8_t)pid;
       break;
     }
-    case 12: {  // MSG_SELECT_EFFECTYN
+    case EP_YGO_MSG_SELECT_EFFECTYN: {
       specs->push_back(option.size() >= 2 ? option.substr(2) : std::string_view());
       if ((rc = need(list_id("yn", option[0]), "yes/no"))) return rc;
       feats[F_YESNO] = (uint8_t)list_id("yn", option[0]);
       break;
     }
-    case 13: {  // MSG_SELECT_YESNO
+    case EP_YGO_MSG_SELECT_YESNO: {
       if ((rc = need(list_id("yn", option[0]), "yes/no"))) return rc;
       feats[F_YESNO] = (uint8_t)list_id("yn", option[0]);
       break;
     }
-    case 10: {  // MSG_SELECT_BATTLECMD
+    case EP_YGO_MSG_SELECT_BATTLECMD: {
       if (option == "m" || option == "e") {
         feats[F_PHASE] = (uint8_t)list_id("bme", option[0]);
       } else {
@@ -1257,15 +1352,15 @@ int parse_option(int msg, const char* option_c, uint8_t feats[9], SpecList* spec
       }
       break;
     }
-    case 14:  // MSG_SELECT_OPTION
+    case EP_YGO_MSG_SELECT_OPTION:
       feats[F_OPTION] = (uint8_t)(option[0] - '0');
       break;
-    case 18: case 24: {  // PLACE / DISFIELD
+    case EP_YGO_MSG_SELECT_PLACE: case EP_YGO_MSG_SELECT_DISFIELD: {
       if ((rc = need(place_id(option), "place"))) return rc;
       feats[F_PLACE] = (uint8_t)place_id(option);
       break;
     }
-    case 141: {  // MSG_ANNOUNCE_ATTRIB: attribute2id.at(1 << (c - '1'))
+    case EP_YGO_MSG_ANNOUNCE_ATTRIB: {  // attribute2id.at(1 << (c - '1'))
       const int sh = option[0] - '1';
       if (sh < 0 || sh > 6) return fail(EP_ERR_INVALID, "option '%s': unknown attribute", option_c);
       feats[F_ATTRIB] = (uint8_t)(sh + 1);
@@ -1338,7 +1433,7 @@ static int emit_record_impl(const ep_ygo_config* cfg, const ygo_raw_state* in, v
   // revealed_: only entries that name an opponent hand card can matter (:1541-1545)
   for (int i = 0; i < in->n_revealed; ++i) {
     uint32_t key;
-    if (in->revealed[i] && spec_key(in->revealed[i], &key) && (key & 0xff) == 1 && ((key >> 8) & 0xff) == 0x02 &&
+    if (in->revealed[i] && spec_key(in->revealed[i], &key) && (key & 0xff) == 1 && ((key >> 8) & 0xff) == EP_YGO_LOCATION_HAND &&
         (key >> 24) == 0) {
       const uint32_t seq = (key >> 16) & 0xff;
       if (seq < 64) h->revealed_hand_mask |= 1ull << seq;
@@ -1438,16 +1533,16 @@ int ep_ygo_history_push(const ep_ygo_config* cfg, uint8_t* ring, int32_t* ha_p, 
   row[off + F_MSG] = feats[F_MSG];
   auto put = [&](int f) { row[off + f] = feats[f]; };
   switch (msg) {
-    case 11: if (option[0] && (strcmp(option, "b") == 0 || strcmp(option, "e") == 0)) put(F_PHASE); else put(F_ACT); break;
-    case 16: if (option[0] == 'c') put(F_CANCEL); else put(F_ACT); break;
-    case 26: if (option[0] == 'f') put(F_CANCEL); break;
-    case 19: put(F_POSITION); break;
-    case 12: put(F_YESNO); break;
-    case 13: put(F_YESNO); break;
-    case 10: if (strcmp(option, "m") == 0 || strcmp(option, "e") == 0) put(F_PHASE); else put(F_ACT); break;
-    case 14: put(F_OPTION); break;
-    case 18: case 24: put(F_PLACE); break;
-    case 141: put(F_ATTRIB); break;
+    case EP_YGO_MSG_SELECT_IDLECMD: if (option[0] && (strcmp(option, "b") == 0 || strcmp(option, "e") == 0)) put(F_PHASE); else put(F_ACT); break;
+    case EP_YGO_MSG_SELECT_CHAIN: if (option[0] == 'c') put(F_CANCEL); else put(F_ACT); break;
+    case EP_YGO_MSG_SELECT_UNSELECT_CARD: if (option[0] == 'f') put(F_CANCEL); break;
+    case EP_YGO_MSG_SELECT_POSITION: put(F_POSITION); break;
+    case EP_YGO_MSG_SELECT_EFFECTYN: put(F_YESNO); break;
+    case EP_YGO_MSG_SELECT_YESNO: put(F_YESNO); break;
+    case EP_YGO_MSG_SELECT_BATTLECMD: if (strcmp(option, "m") == 0 || strcmp(option, "e") == 0) put(F_PHASE); else put(F_ACT); break;
+    case EP_YGO_MSG_SELECT_OPTION: put(F_OPTION); break;
+    case EP_YGO_MSG_SELECT_PLACE: case EP_YGO_MSG_SELECT_DISFIELD: put(F_PLACE); break;
+    case EP_YGO_MSG_ANNOUNCE_ATTRIB: put(F_ATTRIB); break;
     default: break;
   }
   return EP_OK;

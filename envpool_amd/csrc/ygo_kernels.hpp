@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../include/envpool_amd_ygo.h"
+#include "../../include/envpool_amd_ygo_consts.h"  // every ygopro-core value assumed below
 
 namespace ygk {
 
@@ -130,19 +131,24 @@ __device__ __forceinline__ void ft(int x, uint8_t& hi, uint8_t& lo) {  // float_
 
 // location2id (:531-542): DECK 1 .. EXTRA 7; 0 = the reference's .at() throws
 __device__ __forceinline__ uint8_t loc_id(uint32_t loc) {
-  return (loc != 0 && (loc & (loc - 1)) == 0 && loc <= 0x40) ? (uint8_t)(__ffs(loc)) : 0;
+  return (loc != 0 && (loc & (loc - 1)) == 0 && loc <= EP_YGO_LOCATION_EXTRA) ? (uint8_t)(__ffs(loc)) : 0;
 }
 // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8; 0xff = throws
 __device__ __forceinline__ uint8_t pos_id(uint32_t p) {
   switch (p) {
-    case 0x0: return 0; case 0x1: return 1; case 0x2: return 2; case 0x3: return 3; case 0x4: return 4;
-    case 0x5: return 5; case 0x8: return 6; case 0xa: return 7; case 0xc: return 8; default: return 0xff;
+    case 0x0: return 0;  // POS_NONE (:544): overlay materials
+    case EP_YGO_POS_FACEUP_ATTACK: return 1; case EP_YGO_POS_FACEDOWN_ATTACK: return 2; case EP_YGO_POS_ATTACK: return 3;
+    case EP_YGO_POS_FACEUP_DEFENSE: return 4; case EP_YGO_POS_FACEUP: return 5; case EP_YGO_POS_FACEDOWN_DEFENSE: return 6;
+    case EP_YGO_POS_FACEDOWN: return 7; case EP_YGO_POS_DEFENSE: return 8; default: return 0xff;
   }
 }
 __host__ __device__ inline uint32_t type_bit(int j) {  // ascending TYPE_* keys (:607-633)
   // 0x1,0x2,0x4, 0x10..0x4000 (bits 4..14), 0x10000..0x4000000 (bits 16..26)
   return j < 3 ? (1u << j) : (j < 14 ? (1u << (j + 1)) : (1u << (j + 2)));
 }
+static_assert(EP_YGO_TYPE_MONSTER == 0x1u && EP_YGO_TYPE_TRAP == 0x4u && EP_YGO_TYPE_NORMAL == 0x10u && EP_YGO_TYPE_TOKEN == 0x4000u &&
+              EP_YGO_TYPE_QUICKPLAY == 0x10000u && EP_YGO_TYPE_LINK == 0x4000000u && EP_YGO_NUM_TYPES == 25,
+              "type_bit(j) is the j-th TYPE_* key in ascending order");
 
 // Slot of a spec key in the direct-mapped table, or -1 when the key is outside it (then the
 // exact linear scan is used): plain specs by (opponent, location, sequence < max_cards), overlay
@@ -150,9 +156,9 @@ __host__ __device__ inline uint32_t type_bit(int j) {  // ascending TYPE_* keys 
 __host__ __device__ __forceinline__ int spec_slot(uint32_t key, int max_cards) {
   // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
   const uint32_t opp = key & 0xff, loc7 = (key >> 8) & 0xff, seq = (key >> 16) & 0xff, suf = key >> 24;
-  const bool loc_ok = (opp <= 1) & (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
+  const bool loc_ok = (opp <= 1) & (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= EP_YGO_LOCATION_EXTRA);
   const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)max_cards);
-  const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
+  const bool over_ok = loc_ok & (suf != 0) & (loc7 == EP_YGO_LOCATION_MZONE) & (seq < 8) & (suf <= 8);
   const int ti_plain = (int)((opp * 7 + (uint32_t)__builtin_ffs((int)loc7) - 1) * (uint32_t)max_cards + seq);
   const int ti_over = 14 * max_cards + (int)((opp * 8 + seq) * 8 + (suf - 1));
   return plain_ok ? ti_plain : (over_ok ? ti_over : -1);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
       const uint32_t turn_player = (w[0] >> 8) & 0xff, phase = w[6];
       const uint32_t me = to_play == 0 ? w[4] : w[5], op = to_play == 0 ? w[5] : w[4];
       glob0 = ((me >> 8) & 0xff) | ((me & 0xff) << 8) | (((op >> 8) & 0xff) << 16) | ((op & 0xff) << 24);
-      const bool phase_ok = phase != 0 && (phase & (phase - 1)) == 0 && phase <= 0x200;  // phase2id.at()
+      const bool phase_ok = phase != 0 && (phase & (phase - 1)) == 0 && phase <= EP_YGO_PHASE_END;  // phase2id.at()
       if (!phase_ok) bad_u = true;
       glob1 = (phase_ok ? (uint32_t)(__ffs(phase) - 1) : 0u) | (to_play == 0 ? 1u << 8 : 0u) |
               ((uint32_t)to_play == turn_player ? 1u << 16 : 0u);
@@ -662,13 +668,13 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
             const int r = k + (pi ? shift1 : 0);
             const uint32_t loc7 = loc & 0x7f, overlay = loc >> 7;
             // (bitwise &,| on purpose: && and || become branches around exec-mask updates)
-            const bool loc_ok = (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= 0x40);
+            const bool loc_ok = (loc7 != 0) & ((loc7 & (loc7 - 1)) == 0) & (loc7 <= EP_YGO_LOCATION_EXTRA);
             const uint32_t lid = loc_ok ? (uint32_t)__ffs(loc7) : 0u;  // location2id
             // position2id (:546-559): keys {0,1,2,3,4,5,8,0xa,0xc} -> 0..8, one nibble per key; 0xf = throws
             const uint32_t pid = pos < 16 ? (uint32_t)(0xFFF8F7F6FF543210ull >> (4 * (pos & 15))) & 0xf : 0xfu;
             const bool known = ((tq[it].y & kEntryValid) != 0) & (tq[it].x == cw[it][0]);
             const bool revealed = in_hand1 & (seq < 64) & (((hand_mask >> (seq & 63)) & 1ull) != 0);  // :1541-1545
-            bool hide = (pi != 0) & ((pos & 0xa) != 0) & !revealed;                                   // POS_FACEDOWN (:1540)
+            bool hide = (pi != 0) & ((pos & EP_YGO_POS_FACEDOWN) != 0) & !revealed;                                   // POS_FACEDOWN (:1540)
             hide = (hide & (overlay == 0)) | !known;                                                  // :1562-1564
             const uint32_t cid = tq[it].z & 0xffff, tlevel = (tq[it].z >> 16) & 0xff, attr = tq[it].z >> 24, race = tq[it].w & 0xff;
             badv |= (!known | !loc_ok | ((overlay == 0) & (pid == 0xf)) | (!hide & ((attr == 0xff) | (race == 0xff)))) ? 1u : 0u;
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
             // float_transform (:704-710): x % 65536 keeps the low 16 bits of x, sign included
             const uint32_t atk = cw[it][3] & 0xffff, def = cw[it][3] >> 16;
             const uint32_t show = hide ? 0u : 0xffffffffu;
-            const uint32_t b3 = ((loc7 == 0x04) | (loc7 == 0x08) | (loc7 == 0x10)) ? seq + 1 : 0u;  // :1573-1578
+            const uint32_t b3 = ((loc7 == EP_YGO_LOCATION_MZONE) | (loc7 == EP_YGO_LOCATION_SZONE) | (loc7 == EP_YGO_LOCATION_GRAVE)) ? seq + 1 : 0u;  // :1573-1578
             const uint32_t b5 = overlay ? 5u : (pid == 0xf ? 0u : pid);  // overlay: position2id.at(POS_FACEUP)
             const uint32_t w0 = (((cid >> 8) | ((cid & 0xff) << 8)) & show) | (lid << 16) | ((b3 & 0xff) << 24);
             const uint32_t w1 = (ctrl != (uint32_t)to_play ? 1u : 0u) | (b5 << 8) | (overlay << 16) | (((attr == 0xff ? 0u : attr) << 24) & show);
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(kThreads, YGO_OCC) void ygo_encode(Args a) {
             const int ti_plain = (int)((pi * 7 + lid - 1) * (uint32_t)a.max_cards + seq);
             const int ti_over = 14 * a.max_cards + (int)((pi * 8 + seq) * 8 + (suf - 1));
             const bool plain_ok = loc_ok & (suf == 0) & (seq < (uint32_t)a.max_cards);
-            const bool over_ok = loc_ok & (suf != 0) & (loc7 == 0x04) & (seq < 8) & (suf <= 8);
+            const bool over_ok = loc_ok & (suf != 0) & (loc7 == EP_YGO_LOCATION_MZONE) & (seq < 8) & (suf <= 8);
             const int ti = plain_ok ? ti_plain : (over_ok ? ti_over : -1);
             if (ti >= 0) my_spec[YGO_SPEC_IX(ti)] = (uint8_t)(r + 1);
             ti_of[it] = ti;

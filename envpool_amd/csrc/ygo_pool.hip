@@ -114,6 +114,9 @@ struct ep_ygo_pool {
   int max_parts = 4;  // EP_YGO_POOL_PARTS
   alignas(64) int pad_after_counters = 0;
   int sync_commit_rc = EP_OK;
+  std::atomic<int> sync_fail_rc{EP_OK};   // first failing part's code of the batch in flight
+  std::atomic<int> sync_parts_done{0};    // parts of that batch whose count-down has reached zero
+  std::string sync_fail_msg;
   // outcome of callbacks and emits since the last recv
   std::atomic<int> engine_failed{0}, emit_refused{0};
   int64_t recv_timeout_ms = -1;
@@ -182,12 +185,28 @@ void run_slices(ep_ygo_pool* p, const Slice* sl, int k, std::vector<uint8_t>& sc
     const int row0 = part * part_rows, rows = std::min(part_rows, n_total - row0);
     const int64_t c3 = p->trace ? now_ns() : 0;
     int32_t completed = 0;
-    const int rc2 = ep_ygo_commit_slot_rows(p->enc, row0, rows, n_total, &completed);
+    // (once a part has failed the batch cannot complete: the later parts are not launched at all)
+    int rc2 = p->sync_fail_rc.load(std::memory_order_acquire);
+    if (rc2 == EP_OK) {
+      rc2 = ep_ygo_commit_slot_rows(p->enc, row0, rows, n_total, &completed);
+      if (rc2 != EP_OK) {
+        int none = EP_OK;
+        p->sync_fail_rc.compare_exchange_strong(none, rc2);
+        p->sync_fail_msg = epc::g_last_error;  // (only the thread that set the code writes it; read after the last part)
+      }
+    }
     if (p->trace) p->t_commit += now_ns() - c3;
+    // The batch is reported when it is complete, or - after a failure - when the LAST part's
+    // count-down has reached zero: until then other workers are still emitting rows into the slot,
+    // and the next send would rewrite the batch's set-up (slot, sizes, count-downs) under them.
+    const bool last_part = p->sync_parts_done.fetch_add(1, std::memory_order_acq_rel) + 1 == parts;
     if (rc2 == EP_OK && !completed) continue;
+    if (rc2 != EP_OK && !last_part) continue;
+    const int final_rc = p->sync_fail_rc.load(std::memory_order_acquire);
+    if (final_rc != EP_OK) (void)ep_ygo_abort_slot(p->enc);  // the parts that did go out are forgotten: the slot starts clean
     std::lock_guard<std::mutex> lk(p->smu);  // the batch is on its way, or never will be
     if (p->sync_committed != batch) {
-      p->sync_commit_rc = rc2;
+      p->sync_commit_rc = final_rc;
       p->sync_committed = batch;
       p->scv.notify_all();
     }
@@ -302,6 +321,8 @@ int enqueue(ep_ygo_pool* p, int32_t n, const int32_t* env_id, const int32_t* act
     p->sync_parts = (n + p->sync_part_rows - 1) / p->sync_part_rows;
     for (int part = 0; part < p->sync_parts; ++part)
       p->sync_left[part].v.store(std::min(p->sync_part_rows, n - part * p->sync_part_rows), std::memory_order_relaxed);
+    p->sync_fail_rc.store(EP_OK, std::memory_order_relaxed);
+    p->sync_parts_done.store(0, std::memory_order_relaxed);
     ++p->sync_sent;
     p->sync_ids[p->sync_sent & 1].assign(env_id, env_id + n);
   }
@@ -437,7 +458,7 @@ int ep_ygo_pool_recv(ep_ygo_pool* p, int32_t mem_out, ep_batch* out) {
       }
       if (p->sync_commit_rc != EP_OK) {
         p->sync_received = want;
-        return fail(p->sync_commit_rc, "the encoder refused the batch");
+        return fail(p->sync_commit_rc, "the encoder refused the batch: %s", p->sync_fail_msg.c_str());
       }
     }
     const int64_t r2 = p->trace ? now_ns() : 0;

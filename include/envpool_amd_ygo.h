@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "envpool_amd.h"
+#include "envpool_amd_ygo_consts.h" /* the ygopro-core values this path assumes + ep_ygo_check_constants */
 
 #ifdef __cplusplus
 extern "C" {
@@ -233,6 +234,11 @@ int ep_ygo_commit_slot_packed(ep_ygo_encoder* enc, int32_t n, const uint32_t* of
  * StateBuffer of the reference fills row by row in the same way (state_buffer.h:79-129); there the
  * rows are final observations, here each part's encode runs under the emission of the rest. */
 int ep_ygo_commit_slot_rows(ep_ygo_encoder* enc, int32_t row0, int32_t n_rows, int32_t n_total, int32_t* completed);
+/* Gives up a batch some of whose parts went out through ep_ygo_commit_slot_rows (one part's launch
+ * failed, so the batch can never complete): waits for the parts that were launched and forgets them;
+ * the next ep_ygo_acquire_slot / commit starts a clean batch in the same slot. Call it once no other
+ * thread is still committing parts of that batch. */
+int ep_ygo_abort_slot(ep_ygo_encoder* enc);
 /* Counters of the arrival-ordered ring since ep_ygo_async_begin: the time producer threads spent
  * waiting for a free slot (the only place where the GPU side can hold the duel threads up), the
  * records handed out and the batches received. Any pointer may be NULL. */

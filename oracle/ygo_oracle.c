@@ -26,33 +26,36 @@
 
 #include "../include/envpool_amd_ygo.h"
 
-/* ---- ygopro-core constants (common.h; see header comment) ---- */
-#define LOCATION_DECK 0x01
-#define LOCATION_HAND 0x02
-#define LOCATION_MZONE 0x04
-#define LOCATION_SZONE 0x08
-#define LOCATION_GRAVE 0x10
-#define LOCATION_REMOVED 0x20
-#define LOCATION_EXTRA 0x40
-#define LOCATION_OVERLAY 0x80
-#define POS_FACEUP 0x5
-#define POS_FACEDOWN 0xa
-#define QUERY_EQUIP_CARD 0x4000
-#define LEN_EMPTY 4
-#define MSG_SELECT_BATTLECMD 10
-#define MSG_SELECT_IDLECMD 11
-#define MSG_SELECT_EFFECTYN 12
-#define MSG_SELECT_YESNO 13
-#define MSG_SELECT_OPTION 14
-#define MSG_SELECT_CARD 15
-#define MSG_SELECT_CHAIN 16
-#define MSG_SELECT_PLACE 18
-#define MSG_SELECT_POSITION 19
-#define MSG_SELECT_TRIBUTE 20
-#define MSG_SELECT_SUM 23
-#define MSG_SELECT_DISFIELD 24
-#define MSG_SELECT_UNSELECT_CARD 26
-#define MSG_ANNOUNCE_ATTRIB 141
+/* ---- ygopro-core constants: the ONE list in include/envpool_amd_ygo_consts.h (written from memory of
+ * upstream common.h, see there; the product takes them from the same header, and an integrator
+ * checks them against the real common.h with ep_ygo_check_constants) ---- */
+#include "../include/envpool_amd_ygo_consts.h"
+#define LOCATION_DECK EP_YGO_LOCATION_DECK
+#define LOCATION_HAND EP_YGO_LOCATION_HAND
+#define LOCATION_MZONE EP_YGO_LOCATION_MZONE
+#define LOCATION_SZONE EP_YGO_LOCATION_SZONE
+#define LOCATION_GRAVE EP_YGO_LOCATION_GRAVE
+#define LOCATION_REMOVED EP_YGO_LOCATION_REMOVED
+#define LOCATION_EXTRA EP_YGO_LOCATION_EXTRA
+#define LOCATION_OVERLAY EP_YGO_LOCATION_OVERLAY
+#define POS_FACEUP EP_YGO_POS_FACEUP
+#define POS_FACEDOWN EP_YGO_POS_FACEDOWN
+#define QUERY_EQUIP_CARD EP_YGO_QUERY_EQUIP_CARD
+#define LEN_EMPTY EP_YGO_LEN_EMPTY
+#define MSG_SELECT_BATTLECMD EP_YGO_MSG_SELECT_BATTLECMD
+#define MSG_SELECT_IDLECMD EP_YGO_MSG_SELECT_IDLECMD
+#define MSG_SELECT_EFFECTYN EP_YGO_MSG_SELECT_EFFECTYN
+#define MSG_SELECT_YESNO EP_YGO_MSG_SELECT_YESNO
+#define MSG_SELECT_OPTION EP_YGO_MSG_SELECT_OPTION
+#define MSG_SELECT_CARD EP_YGO_MSG_SELECT_CARD
+#define MSG_SELECT_CHAIN EP_YGO_MSG_SELECT_CHAIN
+#define MSG_SELECT_PLACE EP_YGO_MSG_SELECT_PLACE
+#define MSG_SELECT_POSITION EP_YGO_MSG_SELECT_POSITION
+#define MSG_SELECT_TRIBUTE EP_YGO_MSG_SELECT_TRIBUTE
+#define MSG_SELECT_SUM EP_YGO_MSG_SELECT_SUM
+#define MSG_SELECT_DISFIELD EP_YGO_MSG_SELECT_DISFIELD
+#define MSG_SELECT_UNSELECT_CARD EP_YGO_MSG_SELECT_UNSELECT_CARD
+#define MSG_ANNOUNCE_ATTRIB EP_YGO_MSG_ANNOUNCE_ATTRIB
 
 #define YO_OK 0
 #define YO_THROW 6 /* the reference throws (unordered_dense::at / runtime_error) */
@@ -67,26 +70,32 @@ static int location2id(int loc, uint8_t* id) { /* :531-542, id_offset 1 */
   return -1;
 }
 static int position2id(int pos, uint8_t* id) { /* :546-559 */
-  static const int keys[9] = {0x0, 0x1, 0x2, 0x3, 0x4, 0x5, 0x8, 0xa, 0xc};
+  /* std::map iterates in ascending key order: POS_NONE 0x0, then the eight POS_* values sorted */
+  static const int keys[9] = {0x0, EP_YGO_POS_FACEUP_ATTACK, EP_YGO_POS_FACEDOWN_ATTACK, EP_YGO_POS_ATTACK, EP_YGO_POS_FACEUP_DEFENSE,
+                              EP_YGO_POS_FACEUP, EP_YGO_POS_FACEDOWN_DEFENSE, EP_YGO_POS_FACEDOWN, EP_YGO_POS_DEFENSE};
   for (int i = 0; i < 9; ++i)
     if (keys[i] == pos) { *id = (uint8_t)i; return 0; }
   return -1;
 }
 static int attribute2id(uint32_t a, uint8_t* id) { /* :563-571 */
-  static const uint32_t keys[8] = {0x0, 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40};
+  static const uint32_t keys[8] = {0x0, EP_YGO_ATTRIBUTE_EARTH, EP_YGO_ATTRIBUTE_WATER, EP_YGO_ATTRIBUTE_FIRE, EP_YGO_ATTRIBUTE_WIND,
+                                   EP_YGO_ATTRIBUTE_LIGHT, EP_YGO_ATTRIBUTE_DARK, EP_YGO_ATTRIBUTE_DEVINE};
   for (int i = 0; i < 8; ++i)
     if (keys[i] == a) { *id = (uint8_t)i; return 0; }
   return -1;
 }
 static int race2id(uint32_t r, uint8_t* id) { /* :575-605: RACE_NONE, then bit 0 .. bit 25 */
   if (r == 0) { *id = 0; return 0; }
-  for (int i = 0; i < 26; ++i)
-    if (r == (1u << i)) { *id = (uint8_t)(i + 1); return 0; }
+  for (int i = 0; i < EP_YGO_NUM_RACES; ++i)
+    if (r == EP_YGO_RACE(i)) { *id = (uint8_t)(i + 1); return 0; }
   return -1;
 }
 static int phase2id(int ph, uint8_t* id) { /* :644-658: PHASE_DRAW 0x01 .. PHASE_END 0x200 -> 0..9 */
-  for (int i = 0; i < 10; ++i)
-    if (ph == (1 << i)) { *id = (uint8_t)i; return 0; }
+  static const int keys[EP_YGO_NUM_PHASES] = {EP_YGO_PHASE_DRAW, EP_YGO_PHASE_STANDBY, EP_YGO_PHASE_MAIN1, EP_YGO_PHASE_BATTLE_START,
+                                              EP_YGO_PHASE_BATTLE_STEP, EP_YGO_PHASE_DAMAGE, EP_YGO_PHASE_DAMAGE_CAL, EP_YGO_PHASE_BATTLE,
+                                              EP_YGO_PHASE_MAIN2, EP_YGO_PHASE_END};
+  for (int i = 0; i < EP_YGO_NUM_PHASES; ++i)
+    if (ph == keys[i]) { *id = (uint8_t)i; return 0; }
   return -1;
 }
 static int msg2id(int msg, uint8_t* id) { /* :660-669, id_offset 1 */
@@ -113,10 +122,11 @@ static int place2id(const char* s, uint8_t* id) { /* :680-686 */
   return -1;
 }
 /* type2str keys in ascending order (:607-633) */
-static const uint32_t kTypeBits[25] = {0x1, 0x2, 0x4, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200,
-                                       0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x10000, 0x20000, 0x40000,
-                                       0x80000, 0x100000, 0x200000, 0x400000, 0x800000, 0x1000000,
-                                       0x2000000, 0x4000000};
+static const uint32_t kTypeBits[25] = {
+    EP_YGO_TYPE_MONSTER, EP_YGO_TYPE_SPELL, EP_YGO_TYPE_TRAP, EP_YGO_TYPE_NORMAL, EP_YGO_TYPE_EFFECT, EP_YGO_TYPE_FUSION, EP_YGO_TYPE_RITUAL,
+    EP_YGO_TYPE_TRAPMONSTER, EP_YGO_TYPE_SPIRIT, EP_YGO_TYPE_UNION, EP_YGO_TYPE_DUAL, EP_YGO_TYPE_TUNER, EP_YGO_TYPE_SYNCHRO, EP_YGO_TYPE_TOKEN,
+    EP_YGO_TYPE_QUICKPLAY, EP_YGO_TYPE_CONTINUOUS, EP_YGO_TYPE_EQUIP, EP_YGO_TYPE_FIELD, EP_YGO_TYPE_COUNTER, EP_YGO_TYPE_FLIP, EP_YGO_TYPE_TOON,
+    EP_YGO_TYPE_XYZ, EP_YGO_TYPE_PENDULUM, EP_YGO_TYPE_SPSUMMON, EP_YGO_TYPE_LINK};
 
 static void float_transform(int x, uint8_t* hi, uint8_t* lo) { /* :704-710 */
   x = x % 65536;

@@ -464,7 +464,7 @@ def test_headers_are_plain_c_and_cxx(tmp_path):
   import subprocess
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   src = tmp_path / "hdr.c"
-  src.write_text('#include "envpool_amd.h"\n#include "envpool_amd_ygo.h"\nint main(void) { return 0; }\n')
+  src.write_text('#include "envpool_amd.h"\n#include "envpool_amd_ygo.h"\n#include "envpool_amd_ygo_consts.h"\nint main(void) { return 0; }\n')
   for cc, std, extra in (("gcc", "-std=c99", []), ("g++", "-std=c++11", ["-x", "c++"])):
     if not shutil.which(cc):
       continue

@@ -186,6 +186,56 @@ def test_history_push_known_answer():
   assert ring_p.tolist() == want.tolist()
 
 
+@pytest.mark.parametrize("h", GOLD["history_push_cases"], ids=[h["name"] for h in GOLD["history_push_cases"]])
+def test_history_push_cases(h):
+  """More hand-derived ring contents: the DISFIELD branch (Q3, ygopro.h:1758) and several pushes
+  between two WriteState calls followed by the rotated copy-out (Q11, :1959-1962, :1886-1892) -
+  oracle and the product's host ring update both."""
+  n = h["n_history_actions"]
+  cfg = _cfg(n_history_actions=n)
+  L = capi_ygo.lib()
+  ring_o = np.zeros((n, 19), np.uint8)
+  ring_p = ring_o.copy()
+  po = pp = 0
+  for (msg, opt, ids), want_p in zip(h["script"], h["ha_p_after"]):
+    rc, po = ygo_oracle.history_push(cfg, ring_o, po, msg, opt, ids)
+    assert rc == 0 and po == want_p
+    p = C.c_int32(pp)
+    idarr = np.asarray(ids, np.uint16)
+    assert L.ep_ygo_history_push(C.byref(cfg), ring_p.ctypes.data, C.byref(p), msg, opt.encode(), idarr.ctypes.data, len(ids)) == 0
+    pp = p.value
+    assert pp == want_p
+  want = np.array([_full(h["final_ring"].get(str(r), {}), 19) for r in range(n)], np.uint8)
+  assert ring_o.tolist() == want.tolist() and ring_p.tolist() == want.tolist()
+  if "then_write_state" in h:
+    w = h["then_write_state"]
+    st = dict(w["state"], history={f"p{w['state']['to_play']}": ring_p}, ha_p=[pp, pp])
+    arr, keep = ygo_build.batch_of([st], n_hist=n)
+    outs, status = ygo_oracle.write_batch(cfg, ygo_build.make_table(GOLD["table"]), arr, 1)
+    assert status[0] == 0
+    want_h = [_full(w["h_actions_rows"].get(str(r), {}), 19) for r in range(n)]
+    assert outs[11][0].tolist() == want_h
+
+
+def test_check_constants_names_the_first_mismatch():
+  """ep_ygo_check_constants: an integrator fills ep_ygo_core_constants from the real ygopro-core
+  common.h; the library's own values pass, a differing one is named with both values."""
+  L = capi_ygo.lib()
+  c = capi_ygo.CoreConstants()
+  L.ep_ygo_default_constants(C.byref(c))
+  assert list(c.location) == [1, 2, 4, 8, 16, 32, 64, 128] and list(c.msg)[:3] == [11, 16, 15] and c.msg[13] == 141
+  assert c.type[24] == 0x4000000 and c.race[25] == 1 << 25 and c.phase[9] == 0x200 and c.query_equip_card == 0x4000
+  assert L.ep_ygo_check_constants(C.byref(c)) == 0
+  c.location[4] = 0x20            # LOCATION_GRAVE
+  assert L.ep_ygo_check_constants(C.byref(c)) == 1
+  from envpool_amd import capi
+  msg = capi.lib().ep_last_error().decode()
+  assert "LOCATION_GRAVE" in msg and "0x10" in msg and "0x20" in msg
+  L.ep_ygo_default_constants(C.byref(c))
+  c.msg[12] = 25                  # MSG_SELECT_DISFIELD
+  assert L.ep_ygo_check_constants(C.byref(c)) == 1 and "MSG_SELECT_DISFIELD" in capi.lib().ep_last_error().decode()
+
+
 def test_synthetic_states_are_well_formed():
   """The generator feeds both sides of the GPU parity test: most states must encode cleanly, and
   the emitter must accept exactly the states the oracle accepts."""

@@ -57,6 +57,31 @@ def test_known_answers_on_gpu():
       assert got[10][i][int(r)].tolist() == full(row, 19), (case["name"], "actions row", r)
     for r, row in e.get("h_card_ids", {}).items():
       assert got[16][i][int(r)].tolist() == row, (case["name"], "h_card_ids row", r)
+    for key, idx in (("win_reason", 15), ("is_selfplay", 14), ("to_play", 13), ("done", 3), ("step_type", 6)):
+      if key in e:
+        assert int(got[idx][i]) == e[key], (case["name"], key)
+    if "reward" in e:
+      assert float(got[4][i]) == e["reward"], case["name"]
+  # several ring pushes between two WriteStates (Q11), then the rotated copy-out on the device
+  for h in GOLD["history_push_cases"]:
+    if "then_write_state" not in h:
+      continue
+    nh = h["n_history_actions"]
+    cfg_h = capi_ygo.default_config(max_batch=8, n_history_actions=nh)
+    L = capi_ygo.lib()
+    ring = np.zeros((nh, 19), np.uint8)
+    p = C.c_int32(0)
+    for msg, opt, ids in h["script"]:
+      idarr = np.asarray(ids, np.uint16)
+      assert L.ep_ygo_history_push(C.byref(cfg_h), ring.ctypes.data, C.byref(p), msg, opt.encode(), idarr.ctypes.data, len(ids)) == 0
+    w = h["then_write_state"]
+    st = dict(w["state"], history={f"p{w['state']['to_play']}": ring}, ha_p=[p.value, p.value])
+    arr_h, keep_h = ygo_build.batch_of([st], n_hist=nh)
+    recs_h, _ = capi_ygo.emit_records(cfg_h, arr_h, 1)
+    enc_h = capi_ygo.YgoEncoderC(cfg_h, table, len(table))
+    got_h = enc_h.featurize(recs_h)
+    assert got_h[11][0].tolist() == [full(w["h_actions_rows"].get(str(r), {}), 19) for r in range(nh)], h["name"]
+    enc_h.close()
 
 
 @pytest.mark.parametrize("n,seed,kw", [

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <atomic>
 #include <mutex>
 #include <random>
 #include <vector>
@@ -145,8 +146,16 @@ int ep_ygo_commit_slot(ep_ygo_encoder* e, int32_t n) {  // fixed stride: row i a
   e->has_committed = true;
   return EP_OK;
 }
+static std::atomic<int> g_fail_one_part{0};  // the next commit of a part that is not the batch's first fails
+int ep_ygo_abort_slot(ep_ygo_encoder* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->rows_in = 0;
+  return EP_OK;
+}
 int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int32_t n_total, int32_t* completed) {
   std::lock_guard<std::mutex> lk(e->mu);
+  *completed = 0;
+  if (row0 > 0 && g_fail_one_part.exchange(0)) return EP_ERR_HIP;
   if (e->rows_in == 0) e->committed.assign((size_t)n_total, MockRec{});
   for (int i = row0; i < row0 + n_rows; ++i) memcpy(&e->committed[(size_t)i], e->slot.data() + (size_t)i * kStride, sizeof(MockRec));
   e->rows_in += n_rows;
@@ -205,14 +214,23 @@ int main() {
     std::vector<char> done(N, 1);
     for (int it = 0; it < (N > 64 ? 120 : 300); ++it) {
       std::shuffle(ids.begin(), ids.end(), rng);
-      const int n = it % 3 ? N : 1 + (int)(rng() % N);
-      const bool reset = it % 17 == 0;
+      // (it == 50, 600 envs: one part's commit fails - the batch is reported only after every part's
+      // count-down is through, the slot is given up, and the next batch starts clean)
+      const bool inject = N > 64 && it == 50;
+      const int n = (it % 3 || inject || (N > 64 && it == 51)) ? N : 1 + (int)(rng() % N);
+      const bool reset = it % 17 == 0 || (N > 64 && it == 51);
+      if (inject) g_fail_one_part.store(1);
       if (it == 100) g.fail_env = 5;
       if (it == 103) g.fail_env = -1;
       for (int i = 0; i < n; ++i) act[i] = (int32_t)(rng() % 16);
       REQUIRE((reset ? ep_ygo_pool_reset(p, n, ids.data()) : ep_ygo_pool_send(p, n, ids.data(), act.data())) == EP_OK);
       ep_batch b;
       const int rc = ep_ygo_pool_recv(p, EP_MEM_HOST, &b);
+      if (inject) {
+        REQUIRE(rc == EP_ERR_HIP);
+        REQUIRE(g_fail_one_part.load() == 0);
+        continue;  // (the envs were stepped, their rows are lost: the next iteration resets every env)
+      }
       REQUIRE(rc == EP_OK || rc == EP_ERR_INVALID);
       REQUIRE(b.num_rows == n);
       const int32_t* got = (const int32_t*)b.arrays[0].data;
