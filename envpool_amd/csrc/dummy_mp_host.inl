@@ -26,7 +26,7 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     HIP_TRY(hipMemsetAsync(p->mp_sc.counts, 0, 8 * (size_t)p->N, p->stream));
     count_epoch = (uint32_t)++p->mp_count_epoch;
   }
-  if (!force_reset && np_rows > 0) {
+  if (!force_reset && np_rows > 0 && !p->mp_skip_count) {
     hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, p->stream, d_penv,
                        np_rows, p->cfg.env_id_offset, p->N, p->mp_sc.counts, count_epoch);
     HIP_TRY(hipGetLastError());

@@ -169,6 +169,7 @@ struct ep_pool {
   bool poisoned = false;  // a launch failed half-way through a send: the host mirror of the queue is no longer trustworthy
   int rollout_variant = 2;  // EP_ROLLOUT_VARIANT: 2 = LDS-DMA D=4 (default), 0 = LDS-DMA D=6, 1 = register queue
   bool force_generic = false;  // EP_FORCE_GENERIC=1: use the generic kernels everywhere (tests)
+  bool mp_skip_count = false;  // EP_MP_SKIP_COUNT=1: DIAGNOSTIC, wrong results: no histogram launch (what that launch and its boundary cost)
   bool mp_force_ticket = false;  // EP_MP_FORCE_TICKET=1: multi-player tile ids from the ticket counter even when the launch fits (tests)
   // kernel timing
   bool timing = false;
@@ -434,7 +435,7 @@ int max_servers_per_device() {  // EP_SERVER_MAX_PER_DEVICE (read when a pool as
 // Several pools on ONE GPU (a sharded front-end rehearsed on a one-GPU box): a resident kernel
 // beside other pools' launches made every step slower, not faster (4 shards of 16 384 envs:
 // 89 us per front-end step with launches only, 142-177 us with one to four servers resident,
-// profiles/r03/sharded_step_time.txt), so the server is for a pool that has its GPU to itself -
+// profiles/r03/sharded_step_time_*.txt), so the server is for a pool that has its GPU to itself -
 // the deployment it is meant for. EP_SERVER_SHARED_DEVICE=1 at pool creation lifts that (measurements, tests).
 void ring_bell(ep_pool* p, unsigned long long v) {
   if (p->bar_bell) {
@@ -812,6 +813,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   p->device = cfg->device_id;
   if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
   if (const char* ft = getenv("EP_MP_FORCE_TICKET")) p->mp_force_ticket = ft[0] != '0';
+  if (const char* sk = getenv("EP_MP_SKIP_COUNT")) p->mp_skip_count = sk[0] == '1';
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
@@ -931,6 +933,26 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     if (large_bar && !(sb && sb[0] == '0')) {
       if (hipExtMallocWithFlags((void**)&p->bar_bell, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
         HIP_TRY(hipMemset(p->bar_bell, 0, 4096));
+        HIP_TRY(hipDeviceSynchronize());
+        // the attribute promises that a host store reaches this word; see it arrive once before a
+        // step's completion depends on it (otherwise: the leader wake-up through host memory)
+        const unsigned long long probe = 0x0ddba11c0ffeeull;
+        unsigned long long back = 0;
+        *(volatile unsigned long long*)p->bar_bell = probe;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+        _mm_sfence();
+#endif
+        for (int tries = 0; tries < 3 && back != probe; ++tries) {
+          if (tries) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+          HIP_TRY(hipMemcpy(&back, p->bar_bell, sizeof(back), hipMemcpyDeviceToHost));
+        }
+        if (back == probe) {
+          HIP_TRY(hipMemset(p->bar_bell, 0, 4096));
+          HIP_TRY(hipDeviceSynchronize());
+        } else {
+          (void)hipFree(p->bar_bell);
+          p->bar_bell = nullptr;
+        }
       } else {
         (void)hipGetLastError();
         p->bar_bell = nullptr;

@@ -46,7 +46,7 @@ def main(steps=300, N=65536, P=3):
     step()
   check(L.ep_pool_kernel_time_us(h, C.byref(tot), C.byref(cnt), 1))
   print(f"MP P={P} N={N}: {dt * 1e6:.1f} us per step, fused kernel {tot.value / max(1, cnt.value):.2f} us "
-        f"(dbg={os.environ.get('EP_MP_DBG', '0')})", flush=True)
+        f"(EP_MP_SKIP_COUNT={os.environ.get('EP_MP_SKIP_COUNT', '0')})", flush=True)
   mp.close()
 
 

@@ -35,7 +35,7 @@ def main():
         if split > 0:  # launches of two shapes under one name (bench.py --steps 20: clock warm-up vs timed)
           for name, sel in (("shorter", [x for x in d if x < split]), ("longer", [x for x in d if x >= split])):
             if sel:
-              entry[name + f"_than_{int(split)}ns"] = {"calls": len(sel), "avg_ns": sum(sel) / len(sel), "min_ns": min(sel), "max_ns": max(sel)}
+              entry[name + f"_than_{int(split)}ns"] = {"calls": len(sel), "avg_ns": sum(sel) / len(sel), "median_ns": sorted(sel)[len(sel) // 2], "min_ns": min(sel), "max_ns": max(sel)}
         out.setdefault("trace", {})[os.path.relpath(path, root)] = entry
     if "Counter_Name" in cols and "Counter_Value" in cols:
       acc = {}
@@ -43,7 +43,18 @@ def main():
         if keep(r):
           acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
       for k, v in acc.items():
-        out.setdefault("pmc", {})[k] = {"dispatches": len(v), "avg": sum(v) / len(v)}
+        entry = {"dispatches": len(v), "avg": sum(v) / len(v)}
+        # launches of two shapes under one name (bench.py --steps 20: T=128 clock warm-up vs the
+        # timed 20-step launches): counters of the smaller shape are below this fraction of the maximum
+        frac = float(os.environ.get("PMC_SUMMARY_SPLIT_FRAC", "0"))
+        if frac > 0:
+          cut = frac * max(v)
+          for name, sel in (("smaller", [x for x in v if x < cut]), ("larger", [x for x in v if x >= cut])):
+            if sel:
+              srt = sorted(sel)  # the median is the figure of the group's usual shape (the 20-step launches;
+              # the one 5-step --warmup launch among them moves the mean, not the median)
+              entry[name] = {"dispatches": len(sel), "avg": sum(sel) / len(sel), "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1]}
+        out.setdefault("pmc", {})[k] = entry
   print(json.dumps(out, indent=1))
 
 
