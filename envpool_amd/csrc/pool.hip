@@ -70,6 +70,7 @@ struct ep_pool {
   int direct_min_rows = 1;  // EP_DIRECT_MIN_ROWS (4096 until round 2: the staged copies cost a small pool 24 us per step)
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipStream_t own_stream = nullptr;  // the stream the pool created; `stream` is another one while adopted (ep_pool_set_stream)
   // device state
   epk::EnvRec* d_env = nullptr;
   epk::StatPtrs stats{};
@@ -92,6 +93,7 @@ struct ep_pool {
   epk::ErrWords* h_err = nullptr;  // [EQ]
   epk::ErrWords* d_err = nullptr;  // device alias of h_err
   std::vector<uint64_t> deferred_lid;  // [EQ] last launch that may write a deferred word
+  hipEvent_t producer_ev = nullptr;    // ep_pool_step_on_stream: the caller's stream as it was when the step was asked for
   uint32_t sticky_err = 0;  // deferred words folded in when their index came round again: bit 0 action check, 1 id range, 2 duplicate env
   // "written exactly once" (SURVEY.md §5): launch stamps per env
   uint32_t* d_stamp = nullptr;    // [N] device-memory sends: checked by the kernels
@@ -774,6 +776,65 @@ extern "C" {
 const char* ep_last_error(void) { return epc::g_last_error.c_str(); }
 const char* ep_version(void) { return "envpool_amd 0.1 (gfx950)"; }
 
+namespace {
+constexpr int kTermParts = 16;
+struct TermArgs {
+  const uint8_t* done[kTermParts];
+  const uint8_t* trunc[kTermParts];
+  uint8_t* out[kTermParts];
+  int64_t n[kTermParts];
+};
+// out = done & ~trunc, bytewise over up to 16 arrays in one launch: blockIdx.y picks the array, a
+// thread takes 16 bytes (one 16-byte access per array when all three are aligned, bytes otherwise)
+__global__ void terminated_many_kernel(TermArgs a) {
+  const int part = blockIdx.y;
+  const int64_t n = a.n[part];
+  const uint8_t* __restrict__ d = a.done[part];
+  const uint8_t* __restrict__ t = a.trunc[part];
+  uint8_t* __restrict__ o = a.out[part];
+  const bool aligned = ((((uintptr_t)d) | ((uintptr_t)t) | ((uintptr_t)o)) & 15) == 0;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (int64_t)gridDim.x * blockDim.x * 16) {
+    if (aligned && i + 16 <= n) {
+      const uint4 dv = *reinterpret_cast<const uint4*>(d + i), tv = *reinterpret_cast<const uint4*>(t + i);
+      *reinterpret_cast<uint4*>(o + i) = make_uint4(dv.x & ~tv.x, dv.y & ~tv.y, dv.z & ~tv.z, dv.w & ~tv.w);
+    } else {
+      for (int64_t j = i; j < n && j < i + 16; ++j) o[j] = d[j] & (uint8_t)~t[j];
+    }
+  }
+}
+}  // namespace
+
+int ep_terminated_many(int32_t k, const void* const* done, const void* const* trunc, void* const* out, const int64_t* n,
+                       int32_t device, void* stream) {
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  if (k < 0 || (k > 0 && (!done || !trunc || !out || !n))) return fail(EP_ERR_INVALID, "bad argument");
+  for (int i0 = 0; i0 < k; i0 += kTermParts) {
+    TermArgs a{};
+    const int cnt = std::min(kTermParts, k - i0);
+    int64_t longest = 0;
+    for (int i = 0; i < cnt; ++i) {
+      if (n[i0 + i] < 0 || (n[i0 + i] > 0 && (!done[i0 + i] || !trunc[i0 + i] || !out[i0 + i])))
+        return fail(EP_ERR_INVALID, "array %d: null pointer or negative length", i0 + i);
+      a.done[i] = (const uint8_t*)done[i0 + i];
+      a.trunc[i] = (const uint8_t*)trunc[i0 + i];
+      a.out[i] = (uint8_t*)out[i0 + i];
+      a.n[i] = n[i0 + i];
+      longest = std::max(longest, n[i0 + i]);
+    }
+    if (longest == 0) continue;
+    const int64_t groups = std::min<int64_t>((longest + 4095) / 4096, 1024);
+    hipLaunchKernelGGL(terminated_many_kernel, dim3((unsigned)groups, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+  }
+  return EP_OK;
+}
+
+int ep_stream_synchronize(int32_t device, void* stream) {
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return EP_OK;
+}
+
 int32_t ep_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -819,6 +880,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  p->own_stream = p->stream;
   HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
 
   // slot layout
@@ -999,6 +1061,7 @@ int ep_pool_destroy(ep_pool* p) {
   if (p->stats_ev) (void)hipEventDestroy(p->stats_ev);
   if (p->consumer_ev) (void)hipEventDestroy(p->consumer_ev);
   if (p->recv_ev) (void)hipEventDestroy(p->recv_ev);
+  if (p->producer_ev) (void)hipEventDestroy(p->producer_ev);
   for (auto e : p->stage_free) (void)hipEventDestroy(e);
   for (auto e : p->stage_copied) (void)hipEventDestroy(e);
   (void)hipFree(p->d_ring);
@@ -1019,7 +1082,7 @@ int ep_pool_destroy(ep_pool* p) {
   for (auto& sh : p->slots)
     if (sh.host_blk) (void)hipHostFree(sh.host_blk);  // a direct-mode batch nobody received
   epc::retire_blocks(p->blocks);
-  (void)hipStreamDestroy(p->stream);
+  (void)hipStreamDestroy(p->own_stream);
   (void)hipStreamDestroy(p->copy_stream);
   delete p;
   return EP_OK;
@@ -1452,6 +1515,69 @@ int ep_pool_recv_many_on_stream(ep_pool* p, void* consumer_stream, int32_t n, ep
   for (int i = 0; i < n; ++i)
     if ((rc = recv_locked(p, EP_MEM_DEVICE, out + i, lk, &cs))) return rc;
   return EP_OK;
+}
+
+int ep_pool_set_stream(ep_pool* p, void* stream, int32_t own) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::unique_lock<std::mutex> lk(p->mu);
+  int rc = set_device(p);
+  if (rc) return rc;
+  if (p->step_mode != 0) return fail(EP_ERR_INVALID, "ep_pool_set_stream between ep_pool_step_begin and ep_pool_step_end");
+  hipStream_t next = own ? p->own_stream : (hipStream_t)stream;
+  if (next == p->stream) return EP_OK;
+  if ((rc = server_stop(p))) return rc;
+  // everything enqueued so far finishes on the stream it was enqueued on: launches, completion
+  // events and timing events all refer to that stream
+  if ((rc = sync_stream_unlocked(p, &lk))) return rc;
+  if ((rc = drain_timed(p))) return rc;
+  if (p->step_mode != 0) return fail(EP_ERR_INVALID, "ep_pool_set_stream raced with ep_pool_step_begin");
+  p->stream = next;
+  return EP_OK;
+}
+
+int ep_pool_send_on_stream(ep_pool* p, void* stream, int32_t n_arrays, const void* const* arrays,
+                           const int64_t* leading_dims) {
+  if (!p) return fail(EP_ERR_INVALID, "null argument");
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    int rc = set_device(p);
+    if (rc) return rc;
+    hipStream_t cs = (hipStream_t)stream;
+    if (cs != p->stream) {
+      // the actions (and the consumer's reads of the slot this step will refill) come first
+      if (!p->producer_ev) HIP_TRY(hipEventCreateWithFlags(&p->producer_ev, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(p->producer_ev, cs));
+      HIP_TRY(hipStreamWaitEvent(p->stream, p->producer_ev, 0));
+    }
+  }
+  return ep_pool_send(p, n_arrays, arrays, leading_dims, EP_MEM_DEVICE);
+}
+
+int ep_pool_step_on_stream(ep_pool* p, void* stream, int32_t n_arrays, const void* const* arrays,
+                           const int64_t* leading_dims, ep_batch* out) {
+  if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
+  if (p->P > 1) return fail(EP_ERR_INVALID, "ep_pool_step_on_stream needs max_num_players == 1 (see ep_pool_recv_on_stream)");
+  int rc = ep_pool_send_on_stream(p, stream, n_arrays, arrays, leading_dims);
+  if (rc) return rc;
+  return ep_pool_recv_on_stream(p, stream, out);
+}
+
+int ep_pool_poll_errors(ep_pool* p) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  // the words are host memory the kernels write: whatever has arrived is reported, what has not
+  // is seen by the next poll (or by ep_pool_sync, which waits first)
+  uint32_t bits = p->sticky_err;
+  p->sticky_err = 0;
+  for (int w = 0; w < p->EQ; ++w) {
+    if (!p->deferred_err[w]) continue;
+    epk::ErrWords& e = p->h_err[w];
+    if (__atomic_load_n(&e.action_check, __ATOMIC_RELAXED)) { bits |= 1u; e.action_check = 0; }
+    if (__atomic_load_n(&e.env_id_range, __ATOMIC_RELAXED)) { bits |= 2u; e.env_id_range = 0; }
+    if (__atomic_load_n(&e.dup_env, __ATOMIC_RELAXED)) { bits |= 4u; e.dup_env = 0; }
+    if (p->deferred_lid[w] <= p->completed_launch) p->deferred_err[w] = 0;  // its kernels are known to be through
+  }
+  return status_of_err_bits(bits, "poll");
 }
 
 int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {

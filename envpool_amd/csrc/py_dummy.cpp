@@ -298,6 +298,39 @@ struct DummyPool {
     if (!deferred.empty()) throw std::runtime_error(deferred);
     return py::make_tuple(out, b.num_rows, b.num_player_rows);
   }
+  // The stream-ordered step in two halves (ep_pool_send_on_stream, ep_pool_recv_on_stream): the pool
+  // waits for `stream`, `stream` for the rows, the host for nothing. A front-end over several pools
+  // sends to all of them before it receives from any. The recv half returns (address of the batch's
+  // first key, rows): the front-end keeps its views per ring slot and asks _last_descs() only for
+  // a slot it has not seen yet.
+  void send_on_stream(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims, uintptr_t stream) {
+    if (ptrs.size() != 5 || dims.size() != 5) throw std::invalid_argument("need 5 pointers and 5 dims");
+    const void* p[5];
+    for (int i = 0; i < 5; ++i) p[i] = reinterpret_cast<const void*>(ptrs[i]);
+    epy::check(ep_pool_send_on_stream(pool, reinterpret_cast<void*>(stream), 5, p, dims.data()));
+  }
+  py::tuple recv_slot_on_stream(uintptr_t stream) {
+    epy::check(ep_pool_recv_on_stream(pool, reinterpret_cast<void*>(stream), &last_batch));
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows);
+  }
+  py::tuple last_descs() {
+    py::list out;
+    for (int k = 0; k < last_batch.num_keys; ++k) {
+      if (last_batch.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
+      else out.append(epy::device_desc(last_batch.arrays[k]));
+    }
+    return py::make_tuple(out, last_batch.num_rows, last_batch.num_player_rows);
+  }
+  void poll_errors() { epy::check(ep_pool_poll_errors(pool)); }
+  // ep_pool_set_stream: the pool adopts `stream` as its step stream (own = true: back to its own)
+  void set_stream(uintptr_t stream, bool own) {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_set_stream(pool, reinterpret_cast<void*>(stream), own ? 1 : 0);
+    }
+    epy::check(rc);
+  }
   py::tuple server_stats() {
     uint64_t a = 0, b = 0, c = 0;
     int64_t d = 0;
@@ -345,6 +378,7 @@ struct DummyPool {
   }
   void sync() { py::gil_scoped_release rel; epy::check(ep_pool_sync(pool)); }
   int64_t timeout_ms = -1;
+  ep_batch last_batch{};  // of the last _recv_slot_on_stream
   void set_recv_timeout(int64_t ms) { epy::check(ep_pool_set_recv_timeout(pool, ms)); timeout_ms = ms; }
   uintptr_t stream() { return reinterpret_cast<uintptr_t>(ep_pool_stream(pool)); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
@@ -381,6 +415,11 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_step_begin", &DummyPool::step_begin)
       .def("_step_end", &DummyPool::step_end)
       .def("_server_stats", &DummyPool::server_stats)
+      .def("_send_on_stream", &DummyPool::send_on_stream)
+      .def("_recv_slot_on_stream", &DummyPool::recv_slot_on_stream)
+      .def("_last_descs", &DummyPool::last_descs)
+      .def("_poll_errors", &DummyPool::poll_errors)
+      .def("_set_stream", &DummyPool::set_stream, py::arg("stream"), py::arg("own") = false)
       .def("_rollout", &DummyPool::rollout)
       .def("_episode_stats", &DummyPool::episode_stats)
       .def("_checkpoint_save", &DummyPool::checkpoint_save)
@@ -391,4 +430,21 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_handle", &DummyPool::handle)
       .def("close", &DummyPool::close);
   m.def("device_count", []() { return ep_device_count(); });
+  m.def("stream_synchronize", [](int device, uintptr_t stream) {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_stream_synchronize(device, reinterpret_cast<void*>(stream));
+    }
+    epy::check(rc);
+  });
+  // ep_terminated_many: done & ~trunc of k device arrays in one launch on `stream` of `device`
+  m.def("terminated_many", [](const std::vector<uintptr_t>& done, const std::vector<uintptr_t>& trunc, const std::vector<uintptr_t>& out,
+                              const std::vector<int64_t>& n, int device, uintptr_t stream) {
+    if (done.size() != trunc.size() || done.size() != out.size() || done.size() != n.size())
+      throw std::invalid_argument("terminated_many: lists of different lengths");
+    epy::check(ep_terminated_many((int32_t)done.size(), reinterpret_cast<const void* const*>(done.data()),
+                                  reinterpret_cast<const void* const*>(trunc.data()), reinterpret_cast<void* const*>(out.data()), n.data(), device,
+                                  reinterpret_cast<void*>(stream)));
+  });
 }

@@ -206,7 +206,7 @@ class EnvPoolFrontEnd:
       t = self._torch_views[key] = as_torch(desc, self._torch_dev)
     return t
 
-  def step_torch(self, action, env_id=None):
+  def step_torch(self, action, env_id=None, stream_ordered: bool = False):
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
     key) or a dict of them in the shapes step() takes, `env_id` an int32 CUDA tensor or None for all
     envs in order. Returns what step() returns, as torch tensors aliasing the device ring. A sync
@@ -217,47 +217,96 @@ class EnvPoolFrontEnd:
     While that kernel sits on the GPU a device-wide wait (torch.cuda.synchronize()) between two
     steps has to wait for it to leave - the pool's watchdog bounds that to about ten step gaps,
     200 us at least, and falls back to launching per step for callers that keep doing it; use
-    torch.cuda.current_stream().synchronize() instead (include/envpool_amd.h, ep_pool_step)."""
+    torch.cuda.current_stream().synchronize() instead (include/envpool_amd.h, ep_pool_step).
+
+    stream_ordered=True (sync single-player pools stepped as a whole): the step is ENQUEUED on
+    torch's current stream, which the pool adopts as its step stream (ep_pool_set_stream), and the
+    call returns at once - one kernel launch, no host wait, no resident kernel; the result is valid
+    for work queued on that stream afterwards (reading it on the host synchronises the stream like
+    any torch tensor), and a step's error (list_action self-check) surfaces at a later step or at
+    `_sync()` instead of at the step itself."""
     import torch
     if not hasattr(self, "_step_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
     keys = self._spec._action_keys
-    adict = _flatten_action(action) if isinstance(action, dict) else {keys[-1]: action}
     if not hasattr(self, "_torch_dev"):
       self._torch_dev = torch.device("cuda", self.config.get("device_id", 0))
       self._torch_views = {}
     dev = self._torch_dev
-    if env_id is None:
-      if not hasattr(self, "_all_env_ids_torch"):
-        self._all_env_ids_torch = torch.from_numpy(self.all_env_ids).to(dev)
-      env_id = self._all_env_ids_torch
-    adict["env_id"] = env_id
-    adict.setdefault("players.env_id", env_id)
-    if not hasattr(self, "_torch_want"):
-      names = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}
-      self._torch_want = [names[str(spec[0])] for spec in self._spec._action_spec]
-    ptrs, dims, keep = [], [], []
-    for k, want in zip(keys, self._torch_want):
-      t = adict.get(k)
-      if t is None:  # keys the env never reads may be left out: a stand-in of the right length
-        t = adict["players.env_id"] if k.startswith("players.") else env_id
-      if not (isinstance(t, torch.Tensor) and t.is_cuda):
-        raise RuntimeError(f'step_torch: action "{k}" must be a CUDA tensor')
-      if t.dtype != want or not t.is_contiguous():
-        if not hasattr(self, "_torch_stage"):
-          self._torch_stage = {}
-        st = self._torch_stage.get(k)
-        if st is None or st.shape != t.shape:
-          st = self._torch_stage[k] = torch.empty(t.shape, dtype=want, device=dev)
-        st.copy_(t)
-        t = st
-      keep.append(t)
-      ptrs.append(t.data_ptr())
-      dims.append(int(t.shape[0]))
-    # the actions must be complete before the pool reads them: they were produced on torch's stream
-    torch.cuda.current_stream(dev).synchronize()
-    descs, _, _ = self._step_device(ptrs, dims)
-    return self._torch_out(descs, False)
+    # the usual loop passes the same tensors every step: their pointers and sizes are kept
+    sig = None
+    if isinstance(action, torch.Tensor):
+      sig = (None, action.data_ptr(), action.shape, action.dtype)
+    elif isinstance(action, dict) and all(isinstance(v, torch.Tensor) for v in action.values()):
+      sig = tuple((k, v.data_ptr(), v.shape, v.dtype) for k, v in action.items())
+    if sig is not None:
+      sig = (sig, None if env_id is None else (env_id.data_ptr(), env_id.shape, env_id.dtype) if isinstance(env_id, torch.Tensor) else id(env_id))
+    cached = getattr(self, "_step_torch_cached", None)
+    if sig is not None and cached is not None and cached[0] == sig:
+      ptrs, dims, keep = cached[1], cached[2], cached[3]
+    else:
+      adict = _flatten_action(action) if isinstance(action, dict) else {keys[-1]: action}
+      if env_id is None:
+        if not hasattr(self, "_all_env_ids_torch"):
+          self._all_env_ids_torch = torch.from_numpy(self.all_env_ids).to(dev)
+        env_id = self._all_env_ids_torch
+      adict["env_id"] = env_id
+      adict.setdefault("players.env_id", env_id)
+      if not hasattr(self, "_torch_want"):
+        names = {"int32": torch.int32, "float64": torch.float64, "float32": torch.float32}
+        self._torch_want = [names[str(spec[0])] for spec in self._spec._action_spec]
+      ptrs, dims, keep = [], [], []
+      converted = False
+      for k, want in zip(keys, self._torch_want):
+        t = adict.get(k)
+        if t is None:  # keys the env never reads may be left out: a stand-in of the right length
+          t = adict["players.env_id"] if k.startswith("players.") else env_id
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+          raise RuntimeError(f'step_torch: action "{k}" must be a CUDA tensor')
+        if t.dtype != want or not t.is_contiguous():
+          if not hasattr(self, "_torch_stage"):
+            self._torch_stage = {}
+          st = self._torch_stage.get(k)
+          if st is None or st.shape != t.shape:
+            st = self._torch_stage[k] = torch.empty(t.shape, dtype=want, device=dev)
+          st.copy_(t)
+          t = st
+          converted = True  # (a copy of the caller's tensor: to be taken again on every step)
+        keep.append(t)
+        ptrs.append(t.data_ptr())
+        dims.append(int(t.shape[0]))
+      self._step_torch_cached = None if (converted or sig is None) else (sig, ptrs, dims, keep)
+    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    if not hasattr(self, "_slot_results"):
+      self._slot_results = {}
+    h = current_stream_handle(dev)
+    self._keep_actions = keep
+    if stream_ordered and hasattr(self, "_send_on_stream") and dims[0] == self.config["num_envs"] == self.config["batch_size"] \
+        and self.config["max_num_players"] == 1:
+      self._poll_errors()  # what earlier stream-ordered steps have flagged by now
+      if getattr(self, "_adopted_stream", None) != h:
+        self._set_stream(h)
+        self._adopted_stream = h
+      self._send_on_stream(ptrs, dims, h)
+      key = self._recv_slot_on_stream(h)
+      ent = self._slot_results.get(key)
+      if ent is None:
+        ent = slot_entry(self, self._last_descs()[0], dev, self._slot_results, key)
+    else:
+      # the actions must be complete before the pool reads them: they were produced on torch's stream
+      from ..dummy.dummy_envpool import stream_synchronize
+      stream_synchronize(dev.index, h)
+      descs, nrows, _ = self._step_device(ptrs, dims)
+      if self.config["max_num_players"] > 1:  # (the player rows of a slot change from step to step: nothing to keep)
+        return self._torch_out(descs, False)
+      key = (descs[0][0], nrows)
+      ent = self._slot_results.get(key)
+      if ent is None:
+        ent = slot_entry(self, descs, dev, self._slot_results, key)
+    # the result over this ring slot's views is kept (python/streamstep.py); `terminated` is its one
+    # computed element: refreshed by one small launch on torch's stream, like `done > trunc` would be
+    refresh_terminated((ent,), (h,))
+    return ent[0]
 
   def __repr__(self) -> str:
     cfg = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())
@@ -274,6 +323,20 @@ class EnvPoolFrontEnd:
       return state["obs"], info
     terminated = state["done"] > state["trunc"]  # done & ~trunc on booleans, in one pass (one kernel for tensors)
     return state["obs"], state["reward"], terminated, state["trunc"], info
+
+
+  def _term_index(self):
+    """Where `_to(values, False, True)` puts `terminated` (the one element that is computed, not a
+    view of the batch), or None when the flavour has none. See _to_slot."""
+    return 2
+
+  def _to_slot(self, values):
+    """The step result for `values` (views of ONE ring slot) split into what stays true for as long as
+    those views live and what has to be computed on every step: (`_to`'s result as a template,
+    index of `terminated` in it or None, the slot's `done` view, its `trunc` view). A front-end
+    that sees the same slots come round again (python/sharded.py) builds the template once."""
+    state = self._layout.build_dict(values)
+    return self._to(values, False, True), self._term_index(), state["done"], state["trunc"]
 
 
 class GymnasiumFrontEnd(EnvPoolFrontEnd):
@@ -299,6 +362,9 @@ class GymFrontEnd(EnvPoolFrontEnd):
   def action_space(self):
     return self.spec.action_space
 
+  def _term_index(self):
+    return 2 if _gym_is_new_api() else None
+
   def _to(self, values, reset: bool, return_info: bool):
     new_api = _gym_is_new_api()
     state = self._layout.build_dict(values)
@@ -323,6 +389,9 @@ class DMFrontEnd(EnvPoolFrontEnd):
 
   def action_spec(self):
     return self.spec.action_spec()
+
+  def _term_index(self):
+    return None
 
   def _to(self, values, reset: bool, return_info: bool):
     state = self._dm_layout.build_namedtuple("State", values)

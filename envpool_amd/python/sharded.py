@@ -510,13 +510,58 @@ class ShardedTorchMixin:
     for r, ptrs, dims, _ in staged:
       self._shards[r]._send_device(ptrs, dims)
 
-  def step_torch(self, action, env_id=None, owners=None):
-    """step() for a policy on the GPUs. A sync pool stepped as a whole rings every shard's resident
-    server first (ep_pool_step_begin) and then waits for each (ep_pool_step_end): the shards step
-    side by side, no kernel launch, no host hop for the rows."""
+  def _step_on_streams(self, staged):
+    """The whole-pool step in stream order: every shard adopts torch's current stream of its device
+    as its step stream (ep_pool_set_stream; one stream is in order by itself, and a cross-stream
+    wait costs 20-40 us per hop on this platform), the K step kernels are enqueued there
+    (ep_pool_send_on_stream), the batches are described (ep_pool_recv_on_stream) and `terminated`
+    of all parts is refreshed by one more launch; the host waits for nothing. Results are kept per
+    ring slot (python/streamstep.py)."""
+    import torch
+    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    if not hasattr(self, "_sh_slots"):
+      self._sh_slots = [dict() for _ in range(self._K)]
+      self._sh_adopted = [None] * self._K
+    handles = {}
+    ents = []
+    for shard in self._shards:
+      shard._poll_errors()  # what earlier stream-ordered steps have flagged by now (before any shard steps)
+    # every shard is sent to before any is received from (with a stream that is NOT the shard's own, a
+    # recv makes it wait for that shard's rows, and a send after it would wait for them too)
+    hs = []
+    for r, ptrs, dims, _ in staged:
+      dev = self._shard_dev(r)
+      h = handles.get(dev)
+      if h is None:
+        h = handles[dev] = current_stream_handle(dev)
+      hs.append(h)
+      if self._sh_adopted[r] != h:
+        self._shards[r]._set_stream(h)
+        self._sh_adopted[r] = h
+      self._shards[r]._send_on_stream(ptrs, dims, h)
+    for (r, *_), h in zip(staged, hs):
+      shard = self._shards[r]
+      key = shard._recv_slot_on_stream(h)
+      ent = self._sh_slots[r].get(key)
+      ents.append(ent if ent is not None else slot_entry(self, shard._last_descs()[0], self._shard_dev(r), self._sh_slots[r], key))
+    refresh_terminated(ents, hs)  # one launch per device on torch's stream
+    return self._result([e[0] for e in ents], range(self._K))
+
+  def step_torch(self, action, env_id=None, owners=None, stream_ordered=None):
+    """step() for a policy on the GPUs. A sync pool stepped as a whole takes one of two forms.
+    Shards that each have a GPU to themselves ring their resident servers first
+    (ep_pool_step_begin) and then wait for each (ep_pool_step_end): side by side, no kernel launch,
+    blocking like the unsharded step_torch. Shards that SHARE a device cannot each keep a resident
+    kernel there (include/envpool_amd.h, ep_pool_step): they step in stream order
+    (ep_pool_step_on_stream) - the result is valid for work queued on torch's current stream, the
+    host waits for nothing, and a step's error (list_action self-check) surfaces at a later
+    step_torch or `_sync_all()` instead of this one. `stream_ordered` picks the form explicitly."""
     import torch
     self._need_device_path()
     if self._sync and env_id is None and not self._pending and all(hasattr(s, "_step_begin") for s in self._shards):
+      if stream_ordered is None:
+        stream_ordered = len(set(self._devices)) < self._K
+      stream_ordered = bool(stream_ordered) and self._P == 1 and all(hasattr(s, "_send_on_stream") for s in self._shards)
       # the usual loop passes the same tensors every step: their per-shard slices (pointers, sizes) are kept
       flat = action.items() if isinstance(action, dict) else ((None, action),)
       sig = tuple((k, v.data_ptr(), tuple(v.shape), v.dtype, v.device) if isinstance(v, torch.Tensor) else (k, id(v)) for k, v in flat)
@@ -527,9 +572,11 @@ class ShardedTorchMixin:
         staged = [(r,) + self._shard_action(r, d, None) for r, d in self._split_actions(action, None, None)]
         self._staged_sig, self._staged = (None, None) if self._converted else (sig, staged)
         self._staged_devs = {self._shard_dev(r) for r, *_ in staged}
+      self._keep_actions = [k for *_, k in staged]
+      if stream_ordered:
+        return self._step_on_streams(staged)
       for dev in self._staged_devs:
         torch.cuda.current_stream(dev).synchronize()
-      self._keep_actions = [k for *_, k in staged]
       begun = 0
       try:
         for r, ptrs, dims, _ in staged:

@@ -1,0 +1,54 @@
+"""Shared by step_torch of a pool (pool.py, both forms) and the stream-ordered step of a
+sharded front-end (sharded.py:_step_on_streams): what is kept per ring slot, and the one launch that
+refreshes `terminated`.
+
+A pool's ring has `ring_depth` slots and the same device views come round again, so the whole step
+result over a slot's views - obs / info dicts, reward, truncated - is built once per slot
+(`EnvPoolFrontEnd._to_slot`) and handed out again whenever that slot is; the one element that is
+computed rather than viewed, gymnasium's `terminated = done & ~truncated`
+(gymnasium_envpool.py:73-88), gets a tensor of its own per slot that `ep_terminated_many` rewrites on
+the caller's stream on every step, for all parts of a step in one launch per device."""
+
+
+def slot_entry(front, descs, dev, cache, key):
+  """-> [result over the slot's views, None | (done ptr, trunc ptr, terminated ptr, n, device index)]
+  for a batch described by `descs` ((address, shape, typestr) per state key, as `_recv_device` /
+  `_last_descs` return them); kept in `cache` under `key` (the batch's first address and row count)."""
+  import torch
+  from ..interop import as_torch
+  vals = [None if d is None else as_torch(d, dev) for d in descs]
+  tmpl, idx, done, trunc = front._to_slot(vals)
+  ent = [tmpl, None]
+  if idx is not None:
+    if not (type(tmpl) is tuple and done.dtype == torch.bool and trunc.dtype == torch.bool and done.is_contiguous()
+            and trunc.is_contiguous()):
+      raise RuntimeError("stream-ordered step: unexpected result layout")
+    term = torch.empty_like(done)  # rewritten on every step this slot serves; valid as long as its views
+    lst = list(tmpl)
+    lst[idx] = term
+    ent = [tuple(lst), (done.data_ptr(), trunc.data_ptr(), term.data_ptr(), done.numel(), dev.index)]
+  if len(cache) > 1024:
+    cache.clear()
+  cache[key] = ent
+  return ent
+
+
+def refresh_terminated(ents, handles):
+  """terminated = done & ~trunc for every entry that has one, on stream `handles[i]` of its device."""
+  from ..dummy.dummy_envpool import terminated_many
+  by_dev = {}
+  for e, h in zip(ents, handles):
+    if e[1] is not None:
+      by_dev.setdefault((e[1][4], h), []).append(e[1])
+  for (dev_index, h), ps in by_dev.items():
+    terminated_many([p[0] for p in ps], [p[1] for p in ps], [p[2] for p in ps], [p[3] for p in ps], dev_index, h)
+
+
+def current_stream_handle(dev):
+  """The raw hipStream_t of torch's current stream on `dev` as an integer. (torch.cuda.current_stream
+  builds a Stream object, 4 us; the raw getter the compilers in torch use costs a tenth of that.)"""
+  import torch
+  try:
+    return torch._C._cuda_getCurrentRawStream(dev.index)
+  except AttributeError:
+    return torch.cuda.current_stream(dev).cuda_stream

@@ -229,6 +229,40 @@ int ep_pool_recv_on_stream(ep_pool* pool, void* consumer_stream, ep_batch* out);
  * consumer on the GPU without the host waiting for any of them. */
 int ep_pool_recv_many_on_stream(ep_pool* pool, void* consumer_stream, int32_t n, ep_batch* out);
 
+/* One lockstep step in stream order, for a policy that lives on the GPU: the pool's step stream is
+ * made to wait for everything submitted to `stream` (a hipStream_t; NULL = the legacy default
+ * stream) so far - the kernels that wrote the actions, and the consumer's reads of the ring slot this
+ * step refills - then ep_pool_send(EP_MEM_DEVICE), then ep_pool_recv_on_stream(stream): `stream`
+ * waits for the rows, the host for nothing. What ep_pool_step does with a host round trip per step
+ * (6.7 us), this does with none, at the price of ep_pool_recv_on_stream's differences (single-player
+ * pools; errors of a step are reported later: ep_pool_poll_errors / ep_pool_sync). It is the form a
+ * front-end over several pools on ONE device uses, where the resident kernel of ep_pool_step does
+ * not apply. No counterpart in the reference. */
+int ep_pool_step_on_stream(ep_pool* pool, void* stream, int32_t n_arrays, const void* const* arrays,
+                           const int64_t* leading_dims, ep_batch* out);
+/* The send half of it alone: ep_pool_send(EP_MEM_DEVICE) ordered behind everything submitted to
+ * `stream` so far. A caller that steps several pools from one stream sends to ALL of them first and
+ * only then receives (ep_pool_recv_on_stream): each pool then waits for the actions alone, not for the
+ * rows of the pools before it, and their kernels run side by side. */
+int ep_pool_send_on_stream(ep_pool* pool, void* stream, int32_t n_arrays, const void* const* arrays,
+                           const int64_t* leading_dims);
+
+/* Makes `stream` (a hipStream_t of the pool's device; NULL = the legacy default stream) the pool's
+ * step stream - the pool ADOPTS it: every later launch of the pool goes there, and ep_pool_stream()
+ * returns it - or, with own != 0, returns to the stream the pool created. Waits for the pool's
+ * outstanding work first. With the consumer's stream adopted, ep_pool_step_on_stream /
+ * ep_pool_send_on_stream / ep_pool_recv_on_stream on that same stream need no event at all (one
+ * stream is in order by itself); a cross-stream dependency costs 20-40 us per hop on this platform
+ * (profiles/r03/host_latency.txt), which is what a front-end that steps several pools from one
+ * stream saves K times per step. The caller keeps the stream alive until the pool is destroyed or
+ * has returned to its own. No counterpart in the reference. */
+int ep_pool_set_stream(ep_pool* pool, void* stream, int32_t own);
+
+/* Reports (and clears) what the kernels of batches handed out in stream order have flagged SO FAR:
+ * EP_OK, EP_ERR_ACTION_CHECK or EP_ERR_DUP_ENV. Never waits and touches no GPU API - a flag a
+ * running kernel has yet to raise is seen by a later poll, or by ep_pool_sync, which waits first. */
+int ep_pool_poll_errors(ep_pool* pool);
+
 /* `n` consecutive ep_pool_recv calls in one (the natural companion of
  * ep_pool_rollout). `out` points at n ep_batch structs. */
 int ep_pool_recv_many(ep_pool* pool, int32_t mem, int32_t n, ep_batch* out);
@@ -323,6 +357,16 @@ const char* ep_pool_last_rollout_kernel(ep_pool* pool);
 int ep_pool_set_timing(ep_pool* pool, int32_t enabled);
 int ep_pool_kernel_time_us(ep_pool* pool, double* total_us, int64_t* launches, int32_t reset);
 
+/* gymnasium's `terminated = done & ~truncated` (gymnasium_envpool.py:73-88, gym_envpool.py:74-95 new
+ * step API) for k batches in ONE launch on `stream`: out[i][j] = done[i][j] & ~trunc[i][j] over n[i]
+ * bytes of device memory each (the `done` / `trunc` keys of k batches, e.g. one per shard pool of a
+ * front-end). `device`: the arrays' device (made current), or -1 for the current one. */
+int ep_terminated_many(int32_t k, const void* const* done, const void* const* trunc, void* const* out,
+                       const int64_t* n, int32_t device, void* stream);
+/* hipStreamSynchronize(stream) on `device` (-1: the current one), for front-ends that hold a raw
+ * stream handle and must see the producer of the action arrays finished before a blocking
+ * ep_pool_step (which reads them from a resident kernel, outside any stream's order). */
+int ep_stream_synchronize(int32_t device, void* stream);
 int32_t ep_device_count(void);
 const char* ep_last_error(void); /* thread-local text of the last failure */
 const char* ep_version(void);

@@ -232,3 +232,159 @@ def test_server_displaced_rows_and_duplicates():
     assert rc == capi.EP_ERR_DUP_ENV, (case, rc, L.ep_last_error())
     assert b.num_rows == n
   g.close()
+
+
+def test_step_on_stream_no_host_wait_matches_oracle():
+  """ep_pool_step_on_stream through the C ABI: 200 steps of a 65 536-env pool with NO host wait
+  anywhere in the loop - the actions are rewritten by torch kernels on a side stream, the pool's step
+  stream waits for that stream, that stream waits for the rows and copies them out of the ring (whose
+  4 slots come round 50 times) - compared with the oracle afterwards. Then a step with differing
+  list_action lanes: EP_OK at the step, EP_ERR_ACTION_CHECK from ep_pool_poll_errors once the kernel
+  has run, and nothing left for ep_pool_sync to report."""
+  import torch
+
+  from envpool_amd import capi, interop
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  n, steps = 65536, 200
+  g, o, ids, t_ids, t_penv, t_la = _setup(n, 11, dev, torch)
+  rng = np.random.default_rng(8)
+  penv_all = ids[None, :] + (rng.random((steps, n)) < 0.1).astype(np.int32)
+  lane_all = rng.integers(0, 5, size=(steps, n)).astype(np.float64)
+  d_penv_all = torch.from_numpy(penv_all).to(dev)
+  d_lane_all = torch.from_numpy(lane_all).to(dev)
+  keys = [k for k in range(12) if k != 9]
+  dims = (C.c_int64 * 5)(n, n, n, n, n)
+  ptrs = (C.c_void_p * 5)(t_ids.data_ptr(), t_penv.data_ptr(), t_la.data_ptr(), t_ids.data_ptr(), t_ids.data_ptr())
+  b = capi.Batch()
+  side = torch.cuda.Stream(device=dev)
+  store, views = {}, {}
+  torch.cuda.synchronize()
+  with torch.cuda.stream(side):
+    for t in range(steps):
+      t_penv.copy_(d_penv_all[t])
+      t_la.copy_(d_lane_all[t].unsqueeze(1).expand(n, 6))
+      rc = L.ep_pool_step_on_stream(g.handle, C.c_void_p(side.cuda_stream), 5, ptrs, dims, C.byref(b))
+      assert rc == 0, L.ep_last_error()
+      assert b.num_rows == n
+      for k in keys:
+        a = b.arrays[k]
+        v = views.get(a.data)
+        if v is None:
+          shape = tuple(a.shape[i] for i in range(a.ndim))
+          v = views[a.data] = interop.as_torch((a.data, shape, np.dtype(capi._NP[a.dtype]).str), device=dev)
+        if k not in store:
+          store[k] = torch.empty((steps,) + tuple(v.shape), dtype=v.dtype, device=dev)
+        store[k][t].copy_(v)
+  assert len(views) == 4 * len(keys)  # the ring's four slots, again and again
+  side.synchronize()
+  assert L.ep_pool_poll_errors(g.handle) == 0, L.ep_last_error()
+  host = {k: store[k].cpu().numpy() for k in keys}
+  for t in range(steps):
+    o._send([ids, penv_all[t], np.repeat(lane_all[t][:, None], 6, axis=1), ids * 0, ids * 0])
+    want = o._recv()
+    got = [None if k == 9 else host[k][t] for k in range(12)]
+    assert_batches_equal(got, want, f"step {t}")
+  # a flagged step: reported by the poll after the kernel has run, not by the step
+  with torch.cuda.stream(side):
+    t_la[77, 2] = 9.0
+    rc = L.ep_pool_step_on_stream(g.handle, C.c_void_p(side.cuda_stream), 5, ptrs, dims, C.byref(b))
+    assert rc == 0, L.ep_last_error()
+  side.synchronize()
+  assert L.ep_pool_poll_errors(g.handle) == capi.EP_ERR_ACTION_CHECK
+  assert b"self-check" in L.ep_last_error()
+  assert L.ep_pool_poll_errors(g.handle) == 0
+  assert L.ep_pool_sync(g.handle) == 0, L.ep_last_error()
+  # the same loop with the side stream ADOPTED by the pool (ep_pool_set_stream): its kernels run on
+  # that stream, in order with the torch kernels around them, with no event between the two
+  o._send([ids, penv_all[-1], np.repeat(lane_all[-1][:, None], 6, axis=1), ids * 0, ids * 0])
+  o._recv()  # (the flagged step: same state change, the oracle is given clean lanes)
+  assert L.ep_pool_set_stream(g.handle, C.c_void_p(side.cuda_stream), 0) == 0, L.ep_last_error()
+  assert L.ep_pool_stream(g.handle) == side.cuda_stream
+  with torch.cuda.stream(side):
+    for t in range(60):
+      t_penv.copy_(d_penv_all[t])
+      t_la.copy_(d_lane_all[t].unsqueeze(1).expand(n, 6))
+      rc = L.ep_pool_step_on_stream(g.handle, C.c_void_p(side.cuda_stream), 5, ptrs, dims, C.byref(b))
+      assert rc == 0, L.ep_last_error()
+      for k in keys:
+        store[k][t].copy_(views[b.arrays[k].data])
+  side.synchronize()
+  assert L.ep_pool_poll_errors(g.handle) == 0, L.ep_last_error()
+  host = {k: store[k][:60].cpu().numpy() for k in keys}
+  for t in range(60):
+    o._send([ids, penv_all[t], np.repeat(lane_all[t][:, None], 6, axis=1), ids * 0, ids * 0])
+    want = o._recv()
+    assert_batches_equal([None if k == 9 else host[k][t] for k in range(12)], want, f"adopted stream, step {t}")
+  # back on its own stream the blocking calls are what they were
+  assert L.ep_pool_set_stream(g.handle, None, 1) == 0, L.ep_last_error()
+  assert L.ep_pool_stream(g.handle) != side.cuda_stream
+  a = dummy_action(ids)
+  g._send(a); o._send(a)
+  assert_batches_equal(g._recv(), o._recv(), "numpy step after returning to the pool's own stream")
+  g.close()
+  # multi-player pools are refused, as by ep_pool_recv_on_stream
+  g3, _ = _pair(num_envs=256, seed=1, max_num_players=3)
+  assert L.ep_pool_step_on_stream(g3.handle, None, 5, ptrs, dims, C.byref(b)) == capi.EP_ERR_INVALID
+  g3.close()
+
+
+def test_step_torch_stream_ordered_front_end():
+  """env.step_torch(..., stream_ordered=True) of the unsharded Python front-end: the pool adopts
+  torch's current stream, results come from the per-slot cache (python/streamstep.py) with
+  `terminated` refreshed by ep_terminated_many; compared with the oracle at every step (reading a
+  result on the host synchronises the stream), then 300 unread steps in a row, then a flagged step."""
+  import torch
+
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  n, seed = 4096, 4
+  env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=seed)
+  one = DummyOracle(num_envs=n, seed=seed)
+  ids = np.arange(n, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  env.reset_torch()
+  one._reset(ids); one._recv()
+  la = torch.full((n, 6), 1.5, dtype=torch.float64, device=dev)
+  penv = torch.from_numpy(ids).to(dev)
+  act = {"list_action": la, "players.action": penv, "players.id": penv, "players.env_id": penv}
+  rng = np.random.default_rng(1)
+
+  def check(res, want, ctx):
+    obs, rew, term, trunc, info = res
+    assert obs["raw"].cpu().numpy().tobytes() == want[8].tobytes(), ctx
+    assert rew.cpu().numpy().tobytes() == want[4].tobytes() and trunc.cpu().numpy().tobytes() == want[7].tobytes(), ctx
+    assert term.cpu().numpy().tobytes() == (want[3] & ~want[7]).tobytes(), ctx
+    assert info["env_id"].cpu().numpy().tobytes() == want[0].tobytes() and info["elapsed_step"].cpu().numpy().tobytes() == want[2].tobytes(), ctx
+
+  seen_term = False
+  for t in range(40):
+    pe = ids + (rng.random(n) < 0.1).astype(np.int32)
+    penv.copy_(torch.from_numpy(pe).to(dev))
+    res = env.step_torch(act, stream_ordered=True)
+    one._send(dummy_action(ids, players_env_id=pe))
+    want = one._recv()
+    check(res, want, f"step {t}")
+    seen_term = seen_term or bool((want[3] & ~want[7]).any())
+  for t in range(300):
+    res = env.step_torch(act, stream_ordered=True)
+    one._send(dummy_action(ids, players_env_id=pe))
+    want = one._recv()
+    seen_term = seen_term or bool((want[3] & ~want[7]).any())
+  check(res, want, "after 300 unread steps")
+  assert seen_term  # (the comparison of `terminated` saw ones, not only zeros)
+  la[5, 3] = 2.5
+  env.step_torch(act, stream_ordered=True)
+  one._send(dummy_action(ids, players_env_id=pe)); one._recv()
+  torch.cuda.current_stream().synchronize()
+  la[5, 3] = 1.5
+  with pytest.raises(RuntimeError, match="self-check"):
+    env.step_torch(act, stream_ordered=True)
+  # the blocking form and the numpy boundary still work on the same pool (its stream stays adopted)
+  res = env.step_torch(act)
+  one._send(dummy_action(ids, players_env_id=pe))
+  check(res, one._recv(), "blocking step afterwards")
+  a = dummy_action(ids)
+  env._send(a); one._send(a)
+  assert_batches_equal(env._recv(), one._recv(), "numpy step afterwards")
+  env.close()

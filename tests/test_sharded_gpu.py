@@ -254,16 +254,19 @@ def _np(t):
   return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("servers", [True, False])
+@pytest.mark.parametrize("servers", [True, False, "launch"])
 def test_sharded_device_path_sync_matches_one_oracle(servers, monkeypatch):
   """reset_torch / step_torch / send_torch + recv_torch of a sharded sync pool (K = 4 pools on one
   GPU): the rows never leave the device; per shard the result is that shard's block of ONE big
   oracle pool, and .cat() is the whole batch in sent (= ascending id) order. servers = True: the
   shards' resident servers are rung together (ep_pool_step_begin / _end), which pools that share a
   GPU only do when told to (EP_SERVER_SHARED_DEVICE: one pool per GPU is the deployment the
-  server is for); False: what this one-GPU configuration gets by default, one launch per shard."""
+  server is for); False: what this one-GPU configuration gets by default - every shard steps in
+  stream order (ep_pool_step_on_stream), the host waits for nothing and the rows are valid for work
+  on torch's current stream; "launch": the blocking form without servers, one launch + wait per shard."""
   import torch
-  if servers:
+  kw = {} if servers is False else {"stream_ordered": False}
+  if servers is True:
     monkeypatch.setenv("EP_SERVER_SHARED_DEVICE", "1")
     monkeypatch.setenv("EP_SERVER_MAX_PER_DEVICE", "4")
 
@@ -300,12 +303,35 @@ def test_sharded_device_path_sync_matches_one_oracle(servers, monkeypatch):
   for t in range(30):
     pe = ids + (rng.random(G) < 0.1).astype(np.int32)
     penv.copy_(torch.from_numpy(pe).to(dev))
-    res = env.step_torch(act)
+    res = env.step_torch(act, **kw)
     one._send(dummy_action(ids, players_env_id=pe))
     check(res, one._recv(), f"step {t}")
   # the servers were rung (unless the idle watchdog, which this slow loop invites, moved a shard to the launch path)
   served = sum(s._server_stats()[2] for s in env.shards)
-  assert served >= K if servers else served == 0
+  assert served >= K if servers is True else served == 0
+  if servers is False:
+    # many steps with nothing read in between: the host runs ahead of the device, the ring's slots
+    # come round (views and result templates are kept per slot), and the last result is still right
+    for t in range(200):
+      res = env.step_torch(act)
+      one._send(dummy_action(ids, players_env_id=pe))
+      want = one._recv()
+    check(res, want, "after 200 unread steps")
+    # a step whose list_action lanes differ is flagged by its kernel; the flag surfaces at a later
+    # step_torch (or _sync_all), not at the step itself
+    la[n + 5, 3] = 2.5
+    env.step_torch(act)
+    one._send(dummy_action(ids, players_env_id=pe))
+    one._recv()
+    torch.cuda.synchronize()
+    la[n + 5, 3] = 1.5
+    with pytest.raises(RuntimeError, match="self-check"):
+      env.step_torch(act)
+      env._sync_all()
+    # the raising call stepped nothing (every shard is polled before any steps): carry on
+    res = env.step_torch(act)
+    one._send(dummy_action(ids, players_env_id=pe))
+    check(res, one._recv(), "step after the flagged one")
   # send_torch + recv_torch with per-part lists: one shard only, then two shards
   for who in ([2], [0, 3]):
     parts_ids = [torch.from_numpy(ids[r * n:(r + 1) * n].copy()).to(dev) for r in who]

@@ -162,6 +162,101 @@ int main(int argc, char** argv) {
     printf("  server: %llu launches, %llu idle stops, %llu steps served\n", (unsigned long long)launches, (unsigned long long)stops,
            (unsigned long long)served);
   }
+  {
+    // the stream-ordered step (ep_pool_step_on_stream): host time per call with a consumer stream
+    // that does nothing else, and the whole loop including one closing synchronise; then K = 4 pools
+    // of a quarter the size stepped from ONE stream the way python/sharded.py does it (send to all,
+    // then receive from each)
+    const void* a1[5] = {d_ids, d_ids, d_la, d_ids, d_ids};
+    hipStream_t user;
+    (void)hipStreamCreateWithFlags(&user, hipStreamNonBlocking);
+    std::vector<double> ts, tsend, trecv;
+    CK(ep_pool_sync(p));
+    for (int r = 0; r < 300; ++r) CK(ep_pool_step_on_stream(p, user, 5, a1, dims, &b));
+    (void)hipStreamSynchronize(user);
+    const double w0 = now_us();
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      CK(ep_pool_send_on_stream(p, user, 5, a1, dims));
+      const double a1t = now_us();
+      CK(ep_pool_recv_on_stream(p, user, &b));
+      const double a2 = now_us();
+      tsend.push_back(a1t - a0); trecv.push_back(a2 - a1t); ts.push_back(a2 - a0);
+    }
+    (void)hipStreamSynchronize(user);
+    const double w1 = now_us();
+    printf("ep_pool_step_on_stream per step: host %.2f us (send half %.2f, recv half %.2f; medians), %.2f us per step over 2000 steps incl. the closing synchronise\n",
+           median(ts), median(tsend), median(trecv), (w1 - w0) / 2000);
+    CK(ep_pool_poll_errors(p));
+    const int K = 4;
+    ep_pool* q[K];
+    void* qa[K][5];
+    int64_t qd[5];
+    const int nq = N / K;
+    for (int k = 0; k < K; ++k) {
+      ep_dummy_config c2 = cfg;
+      c2.num_envs = nq; c2.batch_size = nq; c2.env_id_offset = k * nq;
+      CK(ep_dummy_pool_create(&c2, &q[k]));
+      std::vector<int32_t> ids(nq);
+      for (int i = 0; i < nq; ++i) ids[i] = k * nq + i;
+      CK(ep_pool_reset(q[k], ids.data(), nq, EP_MEM_HOST));
+      CK(ep_pool_recv(q[k], EP_MEM_DEVICE, &b));
+      qa[k][0] = (char*)d_ids + 4 * (size_t)k * nq; qa[k][1] = qa[k][0];
+      qa[k][2] = (char*)d_la + 48 * (size_t)k * nq; qa[k][3] = qa[k][0]; qa[k][4] = qa[k][0];
+    }
+    for (int i = 0; i < 5; ++i) qd[i] = nq;
+    ep_batch bk[K];
+    auto one = [&]() {
+      for (int k = 0; k < K; ++k) CK(ep_pool_send_on_stream(q[k], user, 5, (const void* const*)qa[k], qd));
+      for (int k = 0; k < K; ++k) CK(ep_pool_recv_on_stream(q[k], user, &bk[k]));
+      return 0;
+    };
+    for (int r = 0; r < 300; ++r) if (one()) return 1;
+    (void)hipStreamSynchronize(user);
+    ts.clear();
+    const double v0 = now_us();
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      if (one()) return 1;
+      ts.push_back(now_us() - a0);
+    }
+    (void)hipStreamSynchronize(user);
+    const double v1 = now_us();
+    printf("%d pools of %d envs from one stream, send to all then receive from each: host %.2f us per step (median), %.2f us per step over 2000 steps incl. the closing synchronise\n",
+           K, nq, median(ts), (v1 - v0) / 2000);
+    // the same two loops with the stream ADOPTED by the pools (ep_pool_set_stream): no events at all
+    CK(ep_pool_set_stream(p, user, 0));
+    for (int r = 0; r < 300; ++r) CK(ep_pool_step_on_stream(p, user, 5, a1, dims, &b));
+    (void)hipStreamSynchronize(user);
+    ts.clear();
+    const double x0 = now_us();
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      CK(ep_pool_step_on_stream(p, user, 5, a1, dims, &b));
+      ts.push_back(now_us() - a0);
+    }
+    (void)hipStreamSynchronize(user);
+    const double x1 = now_us();
+    printf("  with the stream adopted: host %.2f us per step (median), %.2f us per step over 2000 steps incl. the closing synchronise\n", median(ts),
+           (x1 - x0) / 2000);
+    CK(ep_pool_set_stream(p, nullptr, 1));
+    for (int k = 0; k < K; ++k) CK(ep_pool_set_stream(q[k], user, 0));
+    for (int r = 0; r < 300; ++r) if (one()) return 1;
+    (void)hipStreamSynchronize(user);
+    ts.clear();
+    const double y0 = now_us();
+    for (int r = 0; r < 2000; ++r) {
+      const double a0 = now_us();
+      if (one()) return 1;
+      ts.push_back(now_us() - a0);
+    }
+    (void)hipStreamSynchronize(user);
+    const double y1 = now_us();
+    printf("  %d pools with the stream adopted: host %.2f us per step (median), %.2f us per step over 2000 steps incl. the closing synchronise\n", K,
+           median(ts), (y1 - y0) / 2000);
+    for (int k = 0; k < K; ++k) ep_pool_destroy(q[k]);
+    (void)hipStreamDestroy(user);
+  }
   ep_pool_destroy(p);
   return 0;
 }
