@@ -10,6 +10,7 @@ int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count, boo
   a.num_tiles = (cnt + epk::kMpTile - 1) / epk::kMpTile;
   // a CU holds 8 workgroups of 256 threads; half of that is the bound for "all tiles at once"
   a.static_tiles = (a.num_tiles <= 4 * cu_count && !force_ticket) ? 1 : 0;
+  if (a.fold_rows > 0 && !(a.static_tiles && a.sc.barrier)) return fail(EP_ERR_INVALID, "internal: folded histogram without static tiles");
   hipLaunchKernelGGL(epk::mp_step_fused, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
@@ -26,7 +27,20 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     HIP_TRY(hipMemsetAsync(p->mp_sc.counts, 0, 8 * (size_t)p->N, p->stream));
     count_epoch = (uint32_t)++p->mp_count_epoch;
   }
-  if (!force_reset && np_rows > 0 && !p->mp_skip_count) {
+  // The histogram as a phase of the fused kernel instead of a launch of its own (dummy_mp_kernels.hpp,
+  // MpFusedArgs::fold_*): when the send is ONE launch (it fits the head batch and nothing cuts it) whose
+  // workgroups are all resident at once - at most two per CU, a quarter of what a CU holds, so that
+  // other kernels on the device (another pool's resident server, the caller's own) cannot keep one out.
+  bool fold = false;
+  if (p->mp_fold && !force_reset && np_rows > 0 && !p->mp_force_ticket) {
+    const int room0 = (int)(B - p->alloc_count % B);
+    bool cut_inside = false;
+    if (cuts)
+      for (int c : *cuts) cut_inside = cut_inside || (c > 0 && c < n);
+    const int tiles = (n + epk::kMpTile - 1) / epk::kMpTile;
+    fold = n <= room0 && !cut_inside && tiles <= 2 * p->cu_count && p->mp_sc.barrier != nullptr;
+  }
+  if (!force_reset && np_rows > 0 && !p->mp_skip_count && !fold) {
     hipLaunchKernelGGL(epk::mp_count_rows, dim3((np_rows + 255) / 256), dim3(256), 0, p->stream, d_penv,
                        np_rows, p->cfg.env_id_offset, p->N, p->mp_sc.counts, count_epoch);
     HIP_TRY(hipGetLastError());
@@ -81,11 +95,15 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     a.force_reset = force_reset ? 1 : 0;
     a.P = p->P;
     a.first_segment = sh.alloc_count == 0 ? 1 : 0;
+    a.fold_penv = fold ? d_penv : nullptr;
+    a.fold_rows = fold ? np_rows : 0;
+    a.fold_base = p->mp_barrier_total;
     {
       TimedScope ts(p);
       if (int rc = launch_fused(p->stream, a, cnt, p->cu_count, p->mp_force_ticket)) return rc;
     }
     if (!a.static_tiles) p->mp_ticket_total += (uint32_t)a.num_tiles;
+    if (fold) p->mp_barrier_total += (uint32_t)a.num_tiles;
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);

@@ -41,14 +41,15 @@ struct MpScratch {
   unsigned long long* counts;  // [N] {epoch:32 | rows:32}
   unsigned long long* tiles;   // [ceil(max items per launch / 256)] look-back granules
   uint32_t* ticket;            // dynamic tile ids: tile = atomicAdd(ticket, 1) - ticket_base
+  uint32_t* barrier;           // folded histogram: workgroups that have counted their rows, ever (never goes back); may be null
 };
 
-__global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int32_t env_off, int32_t N,
-                              unsigned long long* counts, uint32_t epoch) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  int32_t local = -1;
-  if (j < np_rows) local = penv[j] - env_off;
+// One row of the histogram (the caller passes local = -1 for lanes past the end). All 64 lanes of
+// the wave must call it together.
+// Returns what the second atomic returned (0 for lanes that added nothing): a caller that must know
+// its atomics have been PERFORMED before it goes on waits for that value; one that ignores it gets
+// fire-and-forget atomics.
+__device__ __forceinline__ unsigned long long mp_count_row(int32_t local, int32_t N, int lane, unsigned long long* counts, uint32_t epoch) {
   const bool valid = local >= 0 && local < N;  // rows of envs this pool does not own match nothing
   // rows of one env usually sit next to each other (they are the previous batch's
   // info:players.env_id): the first lane of a run adds the whole run, the others add nothing.
@@ -57,7 +58,7 @@ __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int
   const int32_t prev = __shfl_up(local, 1, 64);
   const bool head = valid && (lane == 0 || prev != local);
   const unsigned long long bounds = __ballot(head || !valid);
-  if (!head) return;
+  if (!head) return 0ull;
   const unsigned long long above = lane == 63 ? 0ull : bounds & ~((2ull << lane) - 1ull);
   const int end = above ? __builtin_ctzll(above) : 64;
   // two single-shot atomics, no retry loop: the max moves a counter of an older send to
@@ -66,7 +67,15 @@ __global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int
   // may name the same env without the threads starving each other.
   unsigned long long* c = counts + local;
   atomicMax(c, (unsigned long long)epoch << 32);
-  atomicAdd(c, (unsigned long long)(end - lane));
+  return atomicAdd(c, (unsigned long long)(end - lane));
+}
+
+__global__ void mp_count_rows(const int32_t* __restrict__ penv, int np_rows, int32_t env_off, int32_t N,
+                              unsigned long long* counts, uint32_t epoch) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t local = -1;
+  if (j < np_rows) local = penv[j] - env_off;
+  (void)mp_count_row(local, N, threadIdx.x & 63, counts, epoch);
 }
 
 struct MpFusedArgs {
@@ -90,6 +99,14 @@ struct MpFusedArgs {
   int32_t n, row0, force_reset, P, first_segment, num_tiles;
   int32_t la_bit0;
   int32_t static_tiles;  // tile id = blockIdx.x (every tile of the launch fits on the device at once)
+  // The histogram folded into this launch (fold_rows > 0; needs static_tiles and a launch that is the
+  // WHOLE send): every workgroup counts its share of the send's action rows, then waits until all
+  // num_tiles workgroups of this launch have (barrier word >= fold_base + num_tiles), and only then
+  // reads its envs' counts. A grid-wide wait: every workgroup must be resident, which static_tiles
+  // with room to spare guarantees (dummy_mp_host.inl).
+  const int32_t* fold_penv;
+  int32_t fold_rows;
+  uint32_t fold_base;
 };
 
 __device__ __forceinline__ int mp_find_item(const int32_t* excl, int r) {
@@ -116,35 +133,79 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   const int64_t i = (int64_t)tile * kMpTile + tid;
   const bool valid = tile < a.num_tiles && i < a.n;
 
+  // ---- what does not depend on the histogram: the item's env, its record, its list_action lanes --
+  int32_t eid = 0, local = -1;
+  bool in_range = false, la_equal = true;
+  EnvRec rec;
+  rec.state = 0; rec.cur_step = 0;
+  if (valid) {
+    eid = a.env_id[i];
+    local = eid - a.pc.env_off;
+    in_range = local >= 0 && local < a.pc.N;
+    if (in_range) {
+      rec = a.env[local];
+      if (!a.force_reset) {
+        if (a.list_action) {
+          const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
+          const double2 v0 = la[0], v1 = la[1], v2 = la[2];
+          la_equal = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+        } else {
+          const int64_t j = (int64_t)a.la_bit0 + i;
+          la_equal = ((a.la_ok[j >> 5] >> (j & 31)) & 1u) != 0;
+        }
+      }
+    }
+  }
+
+  // ---- the histogram, folded in (see MpFusedArgs): count, then wait for every workgroup's count ----
+  if (a.fold_rows > 0) {
+    // No fences anywhere in this phase: an agent-scope release / acquire on this chip writes back /
+    // invalidates the XCD's whole L2 (megabytes of the previous batch's rows: the fused kernel went from
+    // 12 to 42 us with __threadfence() here). Everything that crosses workgroups is an agent-scope
+    // atomic, performed past the per-XCD L2s: the counters, the arrival word, and the loads of both.
+    unsigned seen = 0;
+    for (int base = blockIdx.x * kMpTile; base < a.fold_rows; base += gridDim.x * kMpTile) {
+      const int j = base + tid;
+      int32_t row_local = -1;
+      if (j < a.fold_rows) row_local = a.fold_penv[j] - a.pc.env_off;
+      const unsigned long long old = mp_count_row(row_local, a.pc.N, lane, a.sc.counts, a.count_epoch);
+      seen ^= (unsigned)old ^ (unsigned)(old >> 32);
+    }
+    asm volatile("" ::"v"(seen));  // the atomics' return values have arrived: they have been performed ...
+    __syncthreads();               // ... and so have the whole workgroup's
+    if (tid == 0) {
+      __hip_atomic_fetch_add(a.sc.barrier, 1u, EP_RLX_AGENT);
+      const uint64_t t0 = wall_clock64();
+      unsigned polls = 0;
+      while (__hip_atomic_load(a.sc.barrier, EP_RLX_AGENT) - a.fold_base < (uint32_t)a.num_tiles) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023u) == 0u && wall_clock64() - t0 > 5000000ull) {  // 50 ms at 100 MHz: cannot happen with every
+          a.err->env_id_range = 1u;                                        // workgroup resident; never hang the GPU on a bug
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- env step + shared-row keys -------------------------------------------------------
   int np = 0;
   if (valid) {
-    const int32_t eid = a.env_id[i];
-    const int32_t local = eid - a.pc.env_off;
     StepOut o;
     o.env_id = eid; o.elapsed = 0; o.step_type = 0; o.state = 0; o.raw1 = 0; o.done = 0; o.trunc = 0;
     np = 1;
-    if (local >= 0 && local < a.pc.N) {
-      EnvRec rec = a.env[local];
+    if (in_range) {
       const int32_t L = episode_len(a.pc.seed, eid);
       int32_t action_num = 0;
       if (!a.force_reset && !(rec.state >= L)) {
         if (a.P <= 1) {
           action_num = a.players_env_id[i] == eid ? 1 : 0;  // env.h:115-123 + dummy_envpool.h:179-184
         } else {
-          const unsigned long long c = a.sc.counts[local];
+          // (folded: the counts were written by other workgroups of THIS launch - an agent-scope load, past this XCD's L2)
+          const unsigned long long c = a.fold_rows > 0 ? __hip_atomic_load((gu64*)a.sc.counts + local, EP_RLX_AGENT) : a.sc.counts[local];
           action_num = (uint32_t)(c >> 32) == a.count_epoch ? (int32_t)(uint32_t)c : 0;
         }
-        bool ok;
-        if (a.list_action) {
-          const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
-          const double2 v0 = la[0], v1 = la[1], v2 = la[2];
-          ok = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
-        } else {
-          const int64_t j = (int64_t)a.la_bit0 + i;
-          ok = ((a.la_ok[j >> 5] >> (j & 31)) & 1u) != 0;
-        }
-        if (!ok) a.err->action_check = 1u;
+        if (!la_equal) a.err->action_check = 1u;
       }
       if (!a.force_reset && a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;
       o = step_env(rec, eid, L, a.force_reset != 0, action_num, a.pc.max_episode_steps);

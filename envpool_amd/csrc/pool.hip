@@ -82,6 +82,8 @@ struct ep_pool {
   // multi-player scratch (dummy_mp_kernels.hpp)
   epk::MpScratch mp_sc{};              // histogram counters [N], look-back granules, ticket
   uint32_t mp_ticket_total = 0;        // tiles launched so far (the ticket counter never goes back)
+  uint32_t mp_barrier_total = 0;       // workgroups of folded-histogram launches so far (that counter never goes back either)
+  bool mp_fold = false;                // EP_MP_FOLD=1: the histogram as a phase of the fused kernel (one launch per send)
   uint64_t mp_count_epoch = 0;         // sends so far: low 32 bits tag the row histogram of a send
   uint32_t* d_slot_players = nullptr;  // [Q] player_offset of each slot (device running total)
   uint32_t* h_slot_players = nullptr;  // [EQ] host-mapped: final player_offset per batch generation
@@ -875,6 +877,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (const char* fg = getenv("EP_FORCE_GENERIC")) p->force_generic = fg[0] == '1';
   if (const char* ft = getenv("EP_MP_FORCE_TICKET")) p->mp_force_ticket = ft[0] != '0';
   if (const char* sk = getenv("EP_MP_SKIP_COUNT")) p->mp_skip_count = sk[0] == '1';
+  if (const char* fo = getenv("EP_MP_FOLD")) p->mp_fold = fo[0] == '1';
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
@@ -931,8 +934,9 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     HIP_TRY(hipMemsetAsync(p->mp_sc.counts, 0, 8 * (size_t)p->N, p->stream));
     HIP_TRY(hipMalloc((void**)&p->mp_sc.tiles, 8 * tiles));
     HIP_TRY(hipMemsetAsync(p->mp_sc.tiles, 0, 8 * tiles, p->stream));
-    HIP_TRY(hipMalloc((void**)&p->mp_sc.ticket, 4));
-    HIP_TRY(hipMemsetAsync(p->mp_sc.ticket, 0, 4, p->stream));
+    HIP_TRY(hipMalloc((void**)&p->mp_sc.ticket, 256));  // [0] the ticket, [32] (its own 128 bytes) the folded histogram's arrival counter
+    HIP_TRY(hipMemsetAsync(p->mp_sc.ticket, 0, 256, p->stream));
+    p->mp_sc.barrier = p->mp_sc.ticket + 32;
     HIP_TRY(hipMalloc((void**)&p->d_slot_players, 4 * (size_t)p->Q));
     HIP_TRY(hipMemsetAsync(p->d_slot_players, 0, 4 * (size_t)p->Q, p->stream));
     HIP_TRY(hipHostMalloc((void**)&p->h_slot_players, 4 * (size_t)p->EQ, hipHostMallocMapped));
@@ -1984,6 +1988,7 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   ms.ticket = (uint32_t*)sc;
   ms.tiles = (unsigned long long*)(sc + kNoallocTilesOff);
   ms.counts = (unsigned long long*)(sc + kNoallocCountsOff);
+  ms.barrier = nullptr;  // (no folded histogram here: two launches, as the pool did when this entry point was written)
   const uint32_t epoch = 1;  // the words were just cleared: no tag from an earlier call can match
   if (P > 1 && !force_reset) {
     // every call uses epoch 1, so the previous call's counters carry a matching tag: they are
@@ -2029,6 +2034,9 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
   a.pc.S = S;
   a.slot_players = &result->num_player_rows;
   a.host_players = nullptr;
+  a.fold_penv = nullptr;
+  a.fold_rows = 0;
+  a.fold_base = 0;
   a.row0 = 0;
   a.force_reset = force_reset ? 1 : 0;
   a.P = P;

@@ -273,6 +273,19 @@ def test_multiplayer_ticket_tile_ids(monkeypatch):
   test_multiplayer_ragged_player_dim(4, 1500, 500)
 
 
+def test_multiplayer_folded_histogram(monkeypatch):
+  """EP_MP_FOLD=1: the histogram as a phase of the fused kernel behind a grid-wide wait (one launch
+  per send where the send is one launch of at most two workgroups per CU; DESIGN.md section 3.4: built,
+  measured, slower than two launches, kept behind the switch). Same rows as the oracle: sends that
+  fold (sync pools, 3 and 65 536 envs), sends that do not (an async pool whose sends straddle batches),
+  and a batch whose rows all name one env."""
+  monkeypatch.setenv("EP_MP_FOLD", "1")
+  test_multiplayer_ragged_player_dim(3, 4, 0)
+  test_multiplayer_ragged_player_dim(3, 65536, 0)
+  test_multiplayer_ragged_player_dim(5, 2000, 512)
+  test_multiplayer_all_rows_name_one_env()
+
+
 def test_multiplayer_all_rows_name_one_env():
   """Every players.env_id row names the same env: that env's action_num is the whole row count
   (env.h:128-132), everyone else's 0 - and the row histogram must not crawl on one counter."""
