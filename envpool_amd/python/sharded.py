@@ -513,7 +513,7 @@ class ShardedTorchMixin:
   def _step_on_streams(self, staged):
     """The whole-pool step in stream order: every shard adopts torch's current stream of its device
     as its step stream (ep_pool_set_stream; one stream is in order by itself, and a cross-stream
-    wait costs 20-40 us per hop on this platform), the K step kernels are enqueued there
+    wait per step in each direction measured 113 us per step on this platform), the K step kernels are enqueued there
     (ep_pool_send_on_stream), the batches are described (ep_pool_recv_on_stream) and `terminated`
     of all parts is refreshed by one more launch; the host waits for nothing. Results are kept per
     ring slot (python/streamstep.py)."""

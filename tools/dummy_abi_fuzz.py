@@ -100,6 +100,33 @@ def main(rounds=int(os.environ.get("FUZZ_ROUNDS", "30"))):
       lambda: call_rollout(1, 5, [0] + devp[1:], full, [0] * 5),
       lambda: call_rollout(1, 5, [dev.value, dev.value + 2, dev.value, dev.value, dev.value], full, [0] * 5),
     ]
+    # round 3's entry points: the stream-ordered step and its halves, the error poll, the adopted stream,
+    # the terminated helper, the blocking step
+    def call_sos(n_arrays, arrays, dims, out=True, half=False):
+      ptrs = (C.c_void_p * max(1, len(arrays)))(*arrays) if arrays is not None else None
+      dd = (C.c_int64 * max(1, len(dims)))(*dims) if dims is not None else None
+      if half:
+        return L.ep_pool_send_on_stream(h, None, n_arrays, ptrs, dd)
+      return L.ep_pool_step_on_stream(h, None, n_arrays, ptrs, dd, C.byref(capi.Batch()) if out else None)
+
+    one = (C.c_void_p * 1)(dev.value)
+    menu += [
+      lambda: call_sos(int(rng.choice([0, 4, 6, -1])), devp, good),
+      lambda: call_sos(5, devp, good, out=False),
+      lambda: call_sos(5, [0] * 5, good),
+      lambda: call_sos(5, devp, [2 * N + 1] * 5),
+      lambda: call_sos(5, devp, [-2] * 5, half=True),
+      lambda: call_sos(5, None, good, half=True),
+      lambda: L.ep_pool_step(h, 3, (C.c_void_p * 5)(*devp), (C.c_int64 * 5)(*good), C.byref(capi.Batch())),
+      lambda: L.ep_pool_step(h, 5, (C.c_void_p * 5)(*devp), (C.c_int64 * 5)(*good), None),
+      lambda: L.ep_pool_step_end(h, C.byref(capi.Batch())),                      # no begin before it
+      lambda: L.ep_pool_poll_errors(None),
+      lambda: L.ep_pool_set_stream(None, None, 0),
+      lambda: L.ep_terminated_many(-1, one, one, one, (C.c_int64 * 1)(4), -1, None),
+      lambda: L.ep_terminated_many(1, None, one, one, (C.c_int64 * 1)(4), -1, None),
+      lambda: L.ep_terminated_many(1, one, one, one, (C.c_int64 * 1)(-4), -1, None),
+      lambda: L.ep_terminated_many(1, one, (C.c_void_p * 1)(None), one, (C.c_int64 * 1)(4), -1, None),
+    ]
     if not sync:
       menu.append(lambda: call_rollout(1, 5, devp, full, [0] * 5))          # rollouts are for sync pools
     valid_step(first=True)
@@ -109,6 +136,10 @@ def main(rounds=int(os.environ.get("FUZZ_ROUNDS", "30"))):
         rc = menu[which]()
         assert rc != 0, ("an invalid call was accepted: menu item", which, "pool", N, B, "round", r, it)
         refused += 1
+      if it % 13 == 5:  # valid calls that must change nothing: adopt the legacy stream and come back, poll with nothing flagged
+        assert L.ep_pool_set_stream(h, None, 0) == 0 and L.ep_pool_poll_errors(h) == 0
+        if it % 2:
+          assert L.ep_pool_set_stream(h, None, 1) == 0
       valid_step()
     pool.close()
     L.hipFree(dev)
