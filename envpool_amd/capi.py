@@ -242,6 +242,49 @@ class DummyPoolC:
       out.append(h)
     return out
 
+  def _step_on_stream_via_device(self, action, stream=None, adopt=False):
+    """ep_pool_step_on_stream with host arrays brought to the device first (tests, soaks): the
+    batch it hands out, copied back after `stream` (None: the pool's step stream) has been waited
+    for. adopt=True makes `stream` (None: the legacy default stream) the pool's step stream first
+    (ep_pool_set_stream)."""
+    arrs = [np.ascontiguousarray(action[0], np.int32), np.ascontiguousarray(action[1], np.int32),
+            np.ascontiguousarray(action[2], np.float64), np.ascontiguousarray(action[3], np.int32),
+            np.ascontiguousarray(action[4], np.int32)]
+    L = self._L
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.hipFree.argtypes = [C.c_void_p]
+    dptr = []
+    for a in arrs:
+      d = C.c_void_p()
+      assert L.hipMalloc(C.byref(d), max(256, a.nbytes)) == 0
+      if a.nbytes:
+        assert L.hipMemcpy(d, a.ctypes.data, a.nbytes, 1) == 0
+      dptr.append(d)
+    ptrs = (C.c_void_p * 5)(*[d.value for d in dptr])
+    dims = (C.c_int64 * 5)(*[a.shape[0] for a in arrs])
+    b = Batch()
+    out = []
+    try:
+      if adopt:
+        _check(L.ep_pool_set_stream(self._h, stream, 0))
+      _check(L.ep_pool_step_on_stream(self._h, stream, 5, ptrs, dims, C.byref(b)))
+      _check(L.ep_stream_synchronize(-1, stream if stream is not None else L.ep_pool_stream(self._h)))
+      for k in range(b.num_keys):
+        a = b.arrays[k]
+        if a.dtype == EP_CONTAINER_I32:
+          out.append(None)
+          continue
+        h = np.zeros(tuple(a.shape[i] for i in range(a.ndim)), np.dtype(_NP[a.dtype]))
+        if h.nbytes:
+          assert L.hipMemcpy(h.ctypes.data, a.data, h.nbytes, 2) == 0
+        out.append(h)
+    finally:
+      _check(L.ep_pool_sync(self._h))
+      for d in dptr:
+        L.hipFree(d)
+    return out
+
   def sync(self):
     _check(self._L.ep_pool_sync(self._h))
 

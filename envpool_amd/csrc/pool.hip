@@ -1546,7 +1546,7 @@ int ep_pool_send_on_stream(ep_pool* p, void* stream, int32_t n_arrays, const voi
     std::unique_lock<std::mutex> lk(p->mu);
     int rc = set_device(p);
     if (rc) return rc;
-    hipStream_t cs = (hipStream_t)stream;
+    hipStream_t cs = stream ? (hipStream_t)stream : p->stream;  // (NULL: the pool's step stream, as for ep_pool_recv_on_stream)
     if (cs != p->stream) {
       // the actions (and the consumer's reads of the slot this step will refill) come first
       if (!p->producer_ev) HIP_TRY(hipEventCreateWithFlags(&p->producer_ev, hipEventDisableTiming));

@@ -230,8 +230,9 @@ int ep_pool_recv_on_stream(ep_pool* pool, void* consumer_stream, ep_batch* out);
 int ep_pool_recv_many_on_stream(ep_pool* pool, void* consumer_stream, int32_t n, ep_batch* out);
 
 /* One lockstep step in stream order, for a policy that lives on the GPU: the pool's step stream is
- * made to wait for everything submitted to `stream` (a hipStream_t; NULL = the legacy default
- * stream) so far - the kernels that wrote the actions, and the consumer's reads of the ring slot this
+ * made to wait for everything submitted to `stream` (a hipStream_t; NULL = the pool's step stream
+ * itself, as for ep_pool_recv_on_stream - a caller on the legacy default stream has the pool adopt
+ * it first, ep_pool_set_stream(pool, NULL, 0)) so far - the kernels that wrote the actions, and the consumer's reads of the ring slot this
  * step refills - then ep_pool_send(EP_MEM_DEVICE), then ep_pool_recv_on_stream(stream): `stream`
  * waits for the rows, the host for nothing. What ep_pool_step does with a host round trip per step
  * (6.7 us), this does with none, at the price of ep_pool_recv_on_stream's differences (single-player

@@ -2,6 +2,7 @@
 """GPU box: randomised parity soak of the Dummy pool against the oracle - random pool shapes (sync
 and async, one to three players per env), random send sizes, host arrays through the C ABI.
 Exits 1 on the first differing byte."""
+import ctypes as C
 import os
 import sys
 import time
@@ -20,6 +21,7 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
   rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
   t0 = time.time()
   steps_total = 0
+  user = None  # (SOAK_STREAM) a stream of the caller's, kept for the whole run
   for r in range(rounds):
     n = int(rng.choice([1, 7, 64, 257, 4096, 5000, 20000, 65536]))
     P = int(rng.choice([1, 1, 1, 2, 3]))
@@ -70,6 +72,25 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
         sel = rng.choice(last_ids, size=int(rng.integers(1, len(last_ids) + 1)), replace=True).astype(np.int32)
       penv = sel + (rng.random(len(sel)) < 0.1).astype(np.int32)
       a = dummy_action(sel, penv)
+      if os.environ.get("SOAK_STREAM") == "1" and sync and P == 1 and rng.random() < 0.6:
+        # SOAK_STREAM=1: a whole-pool step in stream order (ep_pool_step_on_stream): 0 - from a stream
+        # of the caller's, ordered against the pool's own by events; 1 - with that stream, or the legacy
+        # default stream, adopted by the pool; 2 - on the pool's own stream
+        mode = int(rng.integers(0, 3))
+        if user is None:
+          user = C.c_void_p()
+          g._L.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+          assert g._L.hipStreamCreate(C.byref(user)) == 0
+        if mode != 1:
+          assert g._L.ep_pool_set_stream(g.handle, None, 1) == 0
+        st = user if mode == 0 or (mode == 1 and rng.random() < 0.5) else None
+        got = g._step_on_stream_via_device(a, st, adopt=(mode == 1))
+        o._send(a)
+        want = o._recv()
+        assert_batches_equal(got, want, f"pool {kw} it {it} stream-ordered mode {mode}")
+        last_ids = np.asarray(want[0])
+        steps_total += len(sel)
+        continue
       if mixed and not sync and len(sel) > 1 and len(set(sel.tolist())) == len(sel) and rng.random() < 0.3:
         # one send as two, the halves through different memories: both write rows of the same batch
         h = len(sel) // 2

@@ -82,6 +82,35 @@ int main(int argc, char** argv) {
            T, timing, median(t_call), median(t_recv), median(t_sync), median(t_dev), median(t_all), cnt ? tot / cnt : 0.0);
   }
   CK(ep_pool_set_timing(p, 0));
+  // the same region in other orders: which waits the runtime makes cheap for each other
+  for (int order = 0; order < 4; ++order) {
+    std::vector<double> t_all, t_last;
+    for (int r = 0; r < 40; ++r) {
+      hipDeviceSynchronize();
+      const double a0 = now_us();
+      CK(ep_pool_rollout(p, T, 5, arrs, dims, strides));
+      if (order == 0) {         // stream-ordered hand-out, then the device-wide wait (what bench.py times)
+        CK(ep_pool_recv_many_on_stream(p, nullptr, T, batches.data()));
+      } else if (order == 1) {  // ep_pool_sync (a stream synchronise) BEFORE receiving, then the device-wide wait
+        CK(ep_pool_sync(p));
+        CK(ep_pool_recv_many(p, EP_MEM_DEVICE, T, batches.data()));
+      } else if (order == 2) {  // stream-ordered hand-out, the pool's stream synchronised, then the device-wide wait
+        CK(ep_pool_recv_many_on_stream(p, nullptr, T, batches.data()));
+        (void)hipStreamSynchronize((hipStream_t)ep_pool_stream(p));
+      } else {                  // blocking hand-out (event wait), then the device-wide wait
+        CK(ep_pool_recv_many(p, EP_MEM_DEVICE, T, batches.data()));
+      }
+      const double a1 = now_us();
+      hipDeviceSynchronize();
+      const double a2 = now_us();
+      t_all.push_back(a2 - a0); t_last.push_back(a2 - a1);
+      CK(ep_pool_sync(p));
+    }
+    static const char* names[4] = {"recv_many_on_stream + device sync", "ep_pool_sync + recv_many + device sync",
+                                   "recv_many_on_stream + stream sync + device sync", "recv_many (event wait) + device sync"};
+    printf("rollout T=%d region, %-50s: total %.1f us, of which the closing device sync %.1f us (medians of 40)\n", T, names[order],
+           median(t_all), median(t_last));
+  }
   // one launch per step, blocking
   {
     const void* a1[5] = {d_ids, d_ids, d_la, d_ids, d_ids};
