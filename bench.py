@@ -134,6 +134,10 @@ def main():
   node_barrier = None
   if dist_on:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:  # (EP_BENCH_FORCE_DIST without a launcher: a one-rank group of our own)
+      os.environ.setdefault("RANK", "0")
+      os.environ.setdefault("WORLD_SIZE", "1")
+      os.environ.setdefault("MASTER_PORT", "29533")
     # gloo carries everything that lives on the host (timings, the barrier's set-up); RCCL carries
     # the one device-side exchange there is, the episode-stat all-gather
     dist.init_process_group("gloo" if rehearse and not rehearse_real_init else "cpu:gloo,cuda:nccl")
@@ -373,7 +377,7 @@ def main():
     k1_us = tot.value / max(1, cnt.value)
     per_step = {
       "value": N * ks / (s1 - s0), "unit": "env-steps/s (this rank)", "ms_per_step": (s1 - s0) / ks * 1e3,
-      "kernel": "dummy_step_sp<10>", "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
+      "kernel": "dummy_step_sp<10, true>", "kernel_us": k1_us, "kernel_GBps": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9,
       "kernel_frac_of_hbm_peak": ALG_BYTES_PER_ENV_STEP * N / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
       "note": "ep_pool_send + blocking ep_pool_recv per lockstep step, device-resident actions",
     }

@@ -578,10 +578,15 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
-  if (p->S == 10)
-    hipExtLaunchKernelGGL(epk::dummy_step_sp<10>, grid, block, 0, st, nullptr, le.stop, 0, a);
+  const bool dev = !force_reset && d_la && a.stamp && !p->force_generic;  // (see dummy_step_sp)
+  if (p->S == 10 && dev)
+    hipExtLaunchKernelGGL((epk::dummy_step_sp<10, true>), grid, block, 0, st, nullptr, le.stop, 0, a);
+  else if (p->S == 10)
+    hipExtLaunchKernelGGL((epk::dummy_step_sp<10, false>), grid, block, 0, st, nullptr, le.stop, 0, a);
+  else if (dev)
+    hipExtLaunchKernelGGL((epk::dummy_step_sp<0, true>), grid, block, 0, st, nullptr, le.stop, 0, a);
   else
-    hipExtLaunchKernelGGL(epk::dummy_step_sp<0>, grid, block, 0, st, nullptr, le.stop, 0, a);
+    hipExtLaunchKernelGGL((epk::dummy_step_sp<0, false>), grid, block, 0, st, nullptr, le.stop, 0, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
 }

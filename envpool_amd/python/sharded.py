@@ -445,8 +445,16 @@ class ShardedTorchMixin:
       if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError(f'send_torch: action "{k}" must be a CUDA tensor')
       if t.dtype != want or not t.is_contiguous() or t.device != dev:
-        t = t.to(device=dev, dtype=want).contiguous()
-        self._converted = True  # a snapshot of the caller's tensor: must be taken again next time
+        # a snapshot of the caller's tensor, to be taken again next time - into a staging tensor the
+        # front-end keeps per shard and key, so that the addresses a shard's resident kernel is bound
+        # to stay the same from step to step (pool.py:step_torch does the same)
+        stage = self.__dict__.setdefault("_sh_stage", {})
+        st = stage.get((r, k))
+        if st is None or st.shape != t.shape:
+          st = stage[(r, k)] = torch.empty(t.shape, dtype=want, device=dev)
+        st.copy_(t)
+        t = st
+        self._converted = True
       keep.append(t)
       ptrs.append(t.data_ptr())
       dims.append(int(t.shape[0]))

@@ -306,6 +306,12 @@ def test_sharded_device_path_sync_matches_one_oracle(servers, monkeypatch):
     res = env.step_torch(act, **kw)
     one._send(dummy_action(ids, players_env_id=pe))
     check(res, one._recv(), f"step {t}")
+  # actions that need a conversion (float32 lanes) are copied into staging tensors the front-end keeps
+  la32 = la.to(torch.float32)
+  for t in range(3):
+    res = env.step_torch(dict(act, list_action=la32), **kw)
+    one._send(dummy_action(ids, players_env_id=pe))
+    check(res, one._recv(), f"float32 lanes, step {t}")
   # the servers were rung (unless the idle watchdog, which this slow loop invites, moved a shard to the launch path)
   served = sum(s._server_stats()[2] for s in env.shards)
   assert served >= K if servers is True else served == 0
