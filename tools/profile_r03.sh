@@ -17,9 +17,11 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/d_wri
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/d20_fetch -- python3 $R/bench.py $A20 > $OUT/d20_fetch.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/d20_write -- python3 $R/bench.py $A20 > $OUT/d20_write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/y_trace -- python3 $R/tools/bench_ygo.py > $OUT/y_trace.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/y_fetch -- python3 $R/tools/bench_ygo.py > $OUT/y_fetch.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/y_write -- python3 $R/tools/bench_ygo.py > $OUT/y_write.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mp_trace -- python3 $R/tools/mp_profile.py > $OUT/mp_trace.log 2>&1 || exit 1
 mkdir -p $OUT/t20 $OUT/t2k $OUT/ty
-cp -r $OUT/d20_trace $OUT/d20_fetch $OUT/d20_write $OUT/t20/; cp -r $OUT/d_trace $OUT/d_fetch $OUT/d_write $OUT/t2k/; cp -r $OUT/y_trace $OUT/ty/
+cp -r $OUT/d20_trace $OUT/d20_fetch $OUT/d20_write $OUT/t20/; cp -r $OUT/d_trace $OUT/d_fetch $OUT/d_write $OUT/t2k/; cp -r $OUT/y_trace $OUT/y_fetch $OUT/y_write $OUT/ty/
 PMC_SUMMARY_SPLIT_FRAC=0.5 PMC_SUMMARY_SPLIT_NS=60000 python3 $R/tools/pmc_summary.py $OUT/t20 dummy_rollout > $OUT/sum/rollout_steps20_summary.json
 python3 $R/tools/pmc_summary.py $OUT/t2k dummy_rollout > $OUT/sum/rollout_summary.json
 python3 $R/tools/pmc_summary.py $OUT/ty ygo_encode 4000000 > $OUT/sum/ygo_summary.json
@@ -32,5 +34,5 @@ grep '^{"metric"' $OUT/d20_trace.log > $OUT/sum/bench_steps20_under_rocprof.json
 grep '^{"metric"' $OUT/d_trace.log > $OUT/sum/bench_under_rocprof.json
 tail -n 2 $OUT/mp_trace.log > $OUT/sum/mp_profile.txt
 # the bulky per-dispatch csv files stay on the box; the summaries travel back
-rm -rf $OUT/d20_trace $OUT/d_trace $OUT/d_fetch $OUT/d_write $OUT/d20_fetch $OUT/d20_write $OUT/y_trace $OUT/mp_trace $OUT/t20 $OUT/t2k $OUT/ty
+rm -rf $OUT/d20_trace $OUT/d_trace $OUT/d_fetch $OUT/d_write $OUT/d20_fetch $OUT/d20_write $OUT/y_trace $OUT/y_fetch $OUT/y_write $OUT/mp_trace $OUT/t20 $OUT/t2k $OUT/ty
 cat $OUT/sum/rollout_steps20_summary.json $OUT/sum/rollout_summary.json $OUT/sum/mp_gap.json
