@@ -5,13 +5,15 @@ namespace epk_mp {
 
 // Fills and launches mp_step_fused for `cnt` items. `sc` / `ticket_base` / epochs: see
 // dummy_mp_kernels.hpp. Shared by the pool path and ep_dummy_send_noalloc.
-int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count, bool force_ticket) {
+int launch_fused(hipStream_t st, epk::MpFusedArgs& a, int cnt, int cu_count, bool force_ticket, bool force_generic = false) {
   a.n = cnt;
   a.num_tiles = (cnt + epk::kMpTile - 1) / epk::kMpTile;
   // a CU holds 8 workgroups of 256 threads; half of that is the bound for "all tiles at once"
   a.static_tiles = (a.num_tiles <= 4 * cu_count && !force_ticket) ? 1 : 0;
   if (a.fold_rows > 0 && !(a.static_tiles && a.sc.barrier)) return fail(EP_ERR_INVALID, "internal: folded histogram without static tiles");
-  hipLaunchKernelGGL(epk::mp_step_fused, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
+  const bool dev = a.P > 1 && !a.force_reset && a.list_action && a.stamp && a.stats.ep_return && a.fold_rows == 0 && !force_generic;
+  if (dev) hipLaunchKernelGGL(epk::mp_step_fused<true>, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
+  else hipLaunchKernelGGL(epk::mp_step_fused<false>, dim3(a.num_tiles), dim3(epk::kMpTile), 0, st, a);
   HIP_TRY(hipGetLastError());
   return EP_OK;
 }
@@ -100,7 +102,7 @@ int enqueue_mp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const
     a.fold_base = p->mp_barrier_total;
     {
       TimedScope ts(p);
-      if (int rc = launch_fused(p->stream, a, cnt, p->cu_count, p->mp_force_ticket)) return rc;
+      if (int rc = launch_fused(p->stream, a, cnt, p->cu_count, p->mp_force_ticket, p->force_generic)) return rc;
     }
     if (!a.static_tiles) p->mp_ticket_total += (uint32_t)a.num_tiles;
     if (fold) p->mp_barrier_total += (uint32_t)a.num_tiles;

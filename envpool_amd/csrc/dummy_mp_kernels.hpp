@@ -120,6 +120,12 @@ __device__ __forceinline__ int mp_find_item(const int32_t* excl, int r) {
   return lo;
 }
 
+// DEV: a multi-player step from device memory with its histogram in a launch of its own (P > 1, not
+// a reset, list_action rows on the device, duplicate stamps on, episode statistics kept, no fold) as
+// a compile-time case, so that everything an item needs from memory is requested in ONE straight
+// line after env_id (see dummy_step_sp in dummy_kernels.hpp: as run-time branches these were six
+// dependent round trips).
+template <bool DEV>
 __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   __shared__ int32_t s_excl[kMpTile + 1];
   __shared__ int32_t s_eid[kMpTile], s_state[kMpTile], s_raw1[kMpTile];
@@ -138,13 +144,24 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   bool in_range = false, la_equal = true;
   EnvRec rec;
   rec.state = 0; rec.cur_step = 0;
+  float ep_ret = 0.f;
+  unsigned long long dev_count = 0ull;
+  uint32_t old_stamp = 0u;  // (stamps are never 0)
   if (valid) {
     eid = a.env_id[i];
     local = eid - a.pc.env_off;
     in_range = local >= 0 && local < a.pc.N;
     if (in_range) {
       rec = a.env[local];
-      if (!a.force_reset) {
+      if constexpr (DEV) {
+        ep_ret = a.stats.ep_return[local];
+        dev_count = a.sc.counts[local];
+        const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
+        const double2 v0 = la[0], v1 = la[1], v2 = la[2];
+        // issued last, looked at last (returns come back in issue order)
+        old_stamp = atomicExch(&a.stamp[local], a.stamp_val);
+        la_equal = (v0.x == v0.y) & (v0.x == v1.x) & (v0.x == v1.y) & (v0.x == v2.x) & (v0.x == v2.y);
+      } else if (!a.force_reset) {
         if (a.list_action) {
           const double2* la = reinterpret_cast<const double2*>(a.list_action + i * 6);
           const double2 v0 = la[0], v1 = la[1], v2 = la[2];
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
   }
 
   // ---- the histogram, folded in (see MpFusedArgs): count, then wait for every workgroup's count ----
-  if (a.fold_rows > 0) {
+  if (!DEV && a.fold_rows > 0) {
     // No fences anywhere in this phase: an agent-scope release / acquire on this chip writes back /
     // invalidates the XCD's whole L2 (megabytes of the previous batch's rows: the fused kernel went from
     // 12 to 42 us with __threadfence() here). Everything that crosses workgroups is an agent-scope
@@ -197,7 +214,12 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
     if (in_range) {
       const int32_t L = episode_len(a.pc.seed, eid);
       int32_t action_num = 0;
-      if (!a.force_reset && !(rec.state >= L)) {
+      if (DEV) {
+        if (!(rec.state >= L)) {
+          action_num = (uint32_t)(dev_count >> 32) == a.count_epoch ? (int32_t)(uint32_t)dev_count : 0;
+          if (!la_equal) a.err->action_check = 1u;
+        }
+      } else if (!a.force_reset && !(rec.state >= L)) {
         if (a.P <= 1) {
           action_num = a.players_env_id[i] == eid ? 1 : 0;  // env.h:115-123 + dummy_envpool.h:179-184
         } else {
@@ -207,20 +229,20 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
         }
         if (!la_equal) a.err->action_check = 1u;
       }
-      if (!a.force_reset && a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;
-      o = step_env(rec, eid, L, a.force_reset != 0, action_num, a.pc.max_episode_steps);
+      if (!DEV && !a.force_reset && a.stamp && stamp_seen(a.stamp, local, a.stamp_val)) a.err->dup_env = 1u;
+      o = step_env(rec, eid, L, DEV ? false : a.force_reset != 0, action_num, a.pc.max_episode_steps);
       a.env[local] = rec;
       np = a.P <= 1 ? 1 : rec.state % (a.P - 1) + 1;
-      if (a.stats.ep_return) {
+      if (DEV || a.stats.ep_return) {
         // return of the env = sum of its players' rewards, reward[k] = float(-k)
         const float r = -0.5f * (float)(np - 1) * (float)np;
-        float acc = (o.elapsed == 0) ? 0.f : a.stats.ep_return[local];
+        float acc = (o.elapsed == 0) ? 0.f : (DEV ? ep_ret : a.stats.ep_return[local]);
         acc += r;
         a.stats.ep_return[local] = acc;
         if (o.done) {
           a.stats.fin_return[local] = acc;
           a.stats.fin_length[local] = o.elapsed;
-          a.stats.ep_count[local] += 1;
+          atomicAdd(&a.stats.ep_count[local], 1);  // (fire and forget: no load in this branch)
         }
       }
     } else {
@@ -367,6 +389,7 @@ __global__ __launch_bounds__(kMpTile) void mp_step_fused(MpFusedArgs a) {
       for (int c = 2; c < S; ++c) row[c] = 0;
     }
   }
+  if (DEV && in_range && old_stamp == a.stamp_val) a.err->dup_env = 1u;  // this launch had stepped the env already
 }
 
 }  // namespace epk

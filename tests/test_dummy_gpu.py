@@ -240,6 +240,10 @@ def test_ring_full_and_action_check():
                                    (4, 70000, 30000)])
 def test_multiplayer_ragged_player_dim(P, n, B):
   """max_num_players > 1: player rows are a device prefix sum."""
+  _mp_ragged(P, n, B)
+
+
+def _mp_ragged(P, n, B, via_device=False):
   g, o = _pair(num_envs=n, batch_size=B, max_num_players=P, seed=2)
   ids = np.arange(n, dtype=np.int32)
   bsz = B or n
@@ -261,8 +265,39 @@ def test_multiplayer_ragged_player_dim(P, n, B):
     perm = rng.permutation(sel.size)
     sel = sel[perm].astype(np.int32)
     a = dummy_action(sel, players_env_id=pe)
-    g._send(a); o._send(a)
+    (g._send_via_device if via_device else g._send)(a); o._send(a)
     outstanding += sel.size
+  return g.episode_stats()
+
+
+@pytest.mark.parametrize("P,n,B", [(3, 40, 0), (3, 40, 16), (4, 5000, 1500), (3, 65536, 0)])
+def test_multiplayer_device_memory_sends(P, n, B):
+  """The same with every send from DEVICE memory: the compile-time device case of the fused kernel
+  (mp_step_fused<true>: record, episode return, histogram count, action rows and the duplicate
+  stamp's exchange requested together), episode statistics included. Then what only that path
+  reports: an env named twice in one send (EP_ERR_DUP_ENV at the recv of that batch) and differing
+  list_action lanes (EP_ERR_ACTION_CHECK)."""
+  from envpool_amd import capi
+  # (the same sends through host memory take the generic kernel: the episode statistics must agree)
+  for x, y in zip(_mp_ragged(P, n, B, via_device=True), _mp_ragged(P, n, B)):
+    assert x.tobytes() == y.tobytes()
+  if B:
+    return
+  g, o = _pair(num_envs=n, max_num_players=P, seed=4)
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  want = o._recv()
+  assert_batches_equal(g._recv(), want, "reset")
+  pe = np.asarray(want[1]).astype(np.int32)
+  a = dummy_action(ids, players_env_id=pe)
+  a[2][n // 2, 3] += 1.0                      # lanes differ for one env
+  g._send_via_device(a)
+  g._recv(allow=(capi.EP_ERR_ACTION_CHECK,))
+  assert g.last_status == capi.EP_ERR_ACTION_CHECK
+  twice = ids.copy(); twice[1] = twice[0]     # one env twice, another not at all
+  g._send_via_device(dummy_action(twice, players_env_id=pe))
+  g._recv(allow=(capi.EP_ERR_DUP_ENV,))
+  assert g.last_status == capi.EP_ERR_DUP_ENV
 
 
 def test_multiplayer_ticket_tile_ids(monkeypatch):
