@@ -179,9 +179,9 @@ int ep_pool_recv(ep_pool* pool, int32_t mem, ep_batch* out);
  * 50 ms, and a caller that keeps running into it (idle stops in a row) is served by the
  * launch-per-step path for the next 8, 16, ... 1024 steps before the server is tried again - so a
  * loop that synchronises the device after every step pays one stall of about 200 us now and then
- * and otherwise the 13 us of send + recv. Use stream-scoped waits (hipStreamSynchronize,
+ * and otherwise the 12 us of send + recv. Use stream-scoped waits (hipStreamSynchronize,
  * hipEventSynchronize, torch.cuda.current_stream().synchronize()) between steps to keep the
- * 4-5 us path; ep_pool_sync stops the server explicitly. It also occupies one workgroup slot
+ * 6.5 us path; ep_pool_sync stops the server explicitly. It also occupies one workgroup slot
  * (256 threads, 12 KB of LDS) on every CU next to the caller's own kernels. */
 int ep_pool_step(ep_pool* pool, int32_t n_arrays, const void* const* arrays, const int64_t* leading_dims,
                  ep_batch* out);
