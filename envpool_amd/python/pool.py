@@ -287,6 +287,7 @@ class EnvPoolFrontEnd:
       if getattr(self, "_adopted_stream", None) != h:
         self._set_stream(h)
         self._adopted_stream = h
+        self._adopted_stream_obj = torch.cuda.current_stream(dev)  # (kept alive for as long as the pool launches on it)
       self._send_on_stream(ptrs, dims, h)
       key = self._recv_slot_on_stream(h)
       ent = self._slot_results.get(key)

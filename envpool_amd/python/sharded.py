@@ -546,6 +546,7 @@ class ShardedTorchMixin:
       if self._sh_adopted[r] != h:
         self._shards[r]._set_stream(h)
         self._sh_adopted[r] = h
+        self.__dict__.setdefault("_sh_stream_objs", {})[r] = torch.cuda.current_stream(dev)  # (kept alive while the shard launches on it)
       self._shards[r]._send_on_stream(ptrs, dims, h)
     for (r, *_), h in zip(staged, hs):
       shard = self._shards[r]
