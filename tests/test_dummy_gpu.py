@@ -270,7 +270,7 @@ def _mp_ragged(P, n, B, via_device=False):
   return g.episode_stats()
 
 
-@pytest.mark.parametrize("P,n,B", [(3, 40, 0), (3, 40, 16), (4, 5000, 1500), (3, 65536, 0)])
+@pytest.mark.parametrize("P,n,B", [(3, 40, 0), (3, 40, 16), (4, 5000, 1500), (3, 16384, 0)])
 def test_multiplayer_device_memory_sends(P, n, B):
   """The same with every send from DEVICE memory: the compile-time device case of the fused kernel
   (mp_step_fused<true>: record, episode return, histogram count, action rows and the duplicate
@@ -312,11 +312,11 @@ def test_multiplayer_folded_histogram(monkeypatch):
   """EP_MP_FOLD=1: the histogram as a phase of the fused kernel behind a grid-wide wait (one launch
   per send where the send is one launch of at most two workgroups per CU; DESIGN.md section 3.4: built,
   measured, slower than two launches, kept behind the switch). Same rows as the oracle: sends that
-  fold (sync pools, 3 and 65 536 envs), sends that do not (an async pool whose sends straddle batches),
+  fold (sync pools, 4 and 32 768 envs), sends that do not (an async pool whose sends straddle batches),
   and a batch whose rows all name one env."""
   monkeypatch.setenv("EP_MP_FOLD", "1")
   test_multiplayer_ragged_player_dim(3, 4, 0)
-  test_multiplayer_ragged_player_dim(3, 65536, 0)
+  test_multiplayer_ragged_player_dim(3, 32768, 0)
   test_multiplayer_ragged_player_dim(5, 2000, 512)
   test_multiplayer_all_rows_name_one_env()
 
