@@ -313,6 +313,26 @@ struct DummyPool {
     epy::check(ep_pool_recv_on_stream(pool, reinterpret_cast<void*>(stream), &last_batch));
     return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows);
   }
+  // ep_pool_recv_many_on_stream: the T batches of a rollout as (first address, rows) each; a
+  // front-end asks _descs_of(i) only for ring slots it has not seen yet.
+  py::list recv_slots_on_stream(uintptr_t stream, int n) {
+    if (n < 0) throw std::invalid_argument("n < 0");
+    last_many.resize((size_t)n);
+    epy::check(ep_pool_recv_many_on_stream(pool, reinterpret_cast<void*>(stream), n, last_many.data()));
+    py::list out;
+    for (const ep_batch& b : last_many) out.append(py::make_tuple(reinterpret_cast<uintptr_t>(b.arrays[0].data), b.num_rows));
+    return out;
+  }
+  py::tuple descs_of(int i) {
+    if (i < 0 || (size_t)i >= last_many.size()) throw std::invalid_argument("no such batch");
+    const ep_batch& b = last_many[(size_t)i];
+    py::list out;
+    for (int k = 0; k < b.num_keys; ++k) {
+      if (b.arrays[k].dtype == EP_CONTAINER_I32) out.append(py::none());
+      else out.append(epy::device_desc(b.arrays[k]));
+    }
+    return py::make_tuple(out, b.num_rows, b.num_player_rows);
+  }
   py::tuple last_descs() {
     py::list out;
     for (int k = 0; k < last_batch.num_keys; ++k) {
@@ -379,6 +399,7 @@ struct DummyPool {
   void sync() { py::gil_scoped_release rel; epy::check(ep_pool_sync(pool)); }
   int64_t timeout_ms = -1;
   ep_batch last_batch{};  // of the last _recv_slot_on_stream
+  std::vector<ep_batch> last_many;  // of the last _recv_slots_on_stream
   void set_recv_timeout(int64_t ms) { epy::check(ep_pool_set_recv_timeout(pool, ms)); timeout_ms = ms; }
   uintptr_t stream() { return reinterpret_cast<uintptr_t>(ep_pool_stream(pool)); }
   uintptr_t handle() { return reinterpret_cast<uintptr_t>(pool); }
@@ -418,6 +439,8 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_send_on_stream", &DummyPool::send_on_stream)
       .def("_recv_slot_on_stream", &DummyPool::recv_slot_on_stream)
       .def("_last_descs", &DummyPool::last_descs)
+      .def("_recv_slots_on_stream", &DummyPool::recv_slots_on_stream)
+      .def("_descs_of", &DummyPool::descs_of)
       .def("_poll_errors", &DummyPool::poll_errors)
       .def("_set_stream", &DummyPool::set_stream, py::arg("stream"), py::arg("own") = false)
       .def("_rollout", &DummyPool::rollout)

@@ -309,6 +309,66 @@ class EnvPoolFrontEnd:
     refresh_terminated((ent,), (h,))
     return ent[0]
 
+  def rollout_torch(self, action, T: Optional[int] = None):
+    """T lockstep steps of every env in ONE kernel launch (ep_pool_rollout), for action sequences
+    that are on the GPU already: `action` is the `list_action` CUDA tensor, float64 `[T, N, 6]` (or
+    `[N, 6]` with `T` given: the same rows every step), or a dict that may also hold
+    "players.env_id", int32 `[T, N]` or `[N]`. Sync single-player pools made with
+    `ring_depth >= T`. Returns a list of T step results, what `step_torch` returns for each step,
+    as views of T ring slots - enqueued on torch's current stream like
+    `step_torch(..., stream_ordered=True)` (the pool adopts that stream; no host wait; errors
+    surface at a later call or `_sync()`). This is the path bench.py times: 1.4 us per
+    65 536-env step instead of 4.5 (one launch per step) or 6.7 (blocking)."""
+    import torch
+    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    if not hasattr(self, "_rollout") or not hasattr(self, "_recv_slots_on_stream"):
+      raise RuntimeError(f"{type(self).__name__} has no fused rollout")
+    if not hasattr(self, "_torch_dev"):
+      self._torch_dev = torch.device("cuda", self.config.get("device_id", 0))
+      self._torch_views = {}
+    dev = self._torch_dev
+    adict = _flatten_action(action) if isinstance(action, dict) else {"list_action": action}
+    la = adict["list_action"]
+    if not (isinstance(la, torch.Tensor) and la.is_cuda):
+      raise RuntimeError('rollout_torch: "list_action" must be a CUDA tensor')
+    n = self.config["num_envs"]
+    if la.dim() == 3:
+      T = int(la.shape[0]) if T is None else T
+      if la.shape[0] != T:
+        raise RuntimeError(f"rollout_torch: list_action has {la.shape[0]} steps, T = {T}")
+    if T is None or T < 1:
+      raise RuntimeError("rollout_torch: give T with a [N, 6] list_action")
+    if tuple(la.shape[-2:]) != (n, self.config["action_num"]):
+      raise RuntimeError(f"rollout_torch: list_action must end in [{n}, {self.config['action_num']}], got {tuple(la.shape)}")
+    if la.dtype != torch.float64 or not la.is_contiguous():
+      la = la.to(torch.float64).contiguous()
+    if not hasattr(self, "_all_env_ids_torch"):
+      self._all_env_ids_torch = torch.from_numpy(self.all_env_ids).to(dev)
+    ids = self._all_env_ids_torch
+    penv = adict.get("players.env_id", ids)
+    if not (isinstance(penv, torch.Tensor) and penv.is_cuda) or tuple(penv.shape[-1:]) != (n,) or (penv.dim() == 2 and penv.shape[0] != T):
+      raise RuntimeError(f"rollout_torch: players.env_id must be a CUDA tensor [{T}, {n}] or [{n}]")
+    if penv.dtype != torch.int32 or not penv.is_contiguous():
+      penv = penv.to(torch.int32).contiguous()
+    if not hasattr(self, "_slot_results"):
+      self._slot_results = {}
+    h = current_stream_handle(dev)
+    self._poll_errors()
+    if getattr(self, "_adopted_stream", None) != h:
+      self._set_stream(h)
+      self._adopted_stream = h
+      self._adopted_stream_obj = torch.cuda.current_stream(dev)
+    self._keep_actions = [la, penv]
+    ptrs = [ids.data_ptr(), penv.data_ptr(), la.data_ptr(), ids.data_ptr(), ids.data_ptr()]
+    strides = [0, n if penv.dim() == 2 else 0, n if la.dim() == 3 else 0, 0, 0]
+    self._rollout(T, ptrs, [n] * 5, strides)
+    ents = []
+    for i, key in enumerate(self._recv_slots_on_stream(h, T)):
+      ent = self._slot_results.get(key)
+      ents.append(ent if ent is not None else slot_entry(self, self._descs_of(i)[0], dev, self._slot_results, key))
+    refresh_terminated(ents, [h] * T)
+    return [e[0] for e in ents]
+
   def __repr__(self) -> str:
     cfg = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())
     return f"{type(self).__name__}({cfg})"

@@ -144,6 +144,52 @@ def test_step_torch_front_end(n):
   assert info["env_id"].cpu().numpy().tolist() == [7, 3, 200] and obs["raw"].cpu().numpy().tobytes() == w[8].tobytes()
 
 
+@pytest.mark.parametrize("n", [4096, 300])
+def test_rollout_torch_front_end(n):
+  """rollout_torch: T lockstep steps in one launch from the Python front-end (n = 4096: the wave
+  kernel; n = 300: the generic one), every step's result equal to the oracle's stepwise - with
+  per-step action rows, then with the same rows every step, twice, so that the 16-slot ring wraps
+  and the cached per-slot results are handed out again."""
+  import torch
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=5, ring_depth=16)
+  o = DummyOracle(num_envs=n, seed=5)
+  ids = np.arange(n, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  env.reset_torch()
+  o._reset(ids); o._recv()
+  T = 12
+  rng = np.random.default_rng(3)
+  pe = ids[None, :] + (rng.random((T, n)) < 0.1).astype(np.int32)
+  lane = rng.integers(0, 4, size=(T, n)).astype(np.float64)
+  la = torch.from_numpy(np.repeat(lane[:, :, None], 6, axis=2)).to(dev)
+
+  def check(res, want, ctx):
+    obs, rew, term, trunc, info = res
+    assert obs["raw"].cpu().numpy().tobytes() == want[8].tobytes(), ctx
+    assert info["env_id"].cpu().numpy().tobytes() == want[0].tobytes() and info["elapsed_step"].cpu().numpy().tobytes() == want[2].tobytes(), ctx
+    assert rew.cpu().numpy().tobytes() == want[4].tobytes() and trunc.cpu().numpy().tobytes() == want[7].tobytes(), ctx
+    assert term.cpu().numpy().tobytes() == (want[3] & ~want[7]).tobytes(), ctx
+
+  out = env.rollout_torch({"list_action": la, "players.env_id": torch.from_numpy(pe).to(dev)})
+  assert len(out) == T
+  for t in range(T):
+    o._send(dummy_action(ids, players_env_id=pe[t]))
+    check(out[t], o._recv(), f"per-step rows, t={t}")
+  for rnd in range(2):
+    out = env.rollout_torch(la[0], T=T)
+    for t in range(T):
+      o._send(dummy_action(ids))
+      check(out[t], o._recv(), f"same rows, round {rnd}, t={t}")
+  # a step in stream order and a blocking step on the same pool afterwards
+  check(env.step_torch({"list_action": la[0]}, stream_ordered=True), (o._send(dummy_action(ids)), o._recv())[1], "stream-ordered step after")
+  check(env.step_torch({"list_action": la[0]}), (o._send(dummy_action(ids)), o._recv())[1], "blocking step after")
+  with pytest.raises(Exception):
+    env.rollout_torch(la[0], T=17)  # more steps than ring slots
+  env.close()
+
+
 def test_close_releases_the_pool():
   """Additive close() (gym's convention): the device memory goes at once, later calls are refused."""
   import envpool_amd

@@ -73,6 +73,25 @@ for n, k in ((65536, 1), (65536, 4), (65536, 8), (524288, 8)) if os.environ.get(
     print(line, flush=True)
     env.close()
 
+# the fused rollout from the Python front-end: T = 128 steps per call
+if os.environ.get('ONLY_K4') != '1':
+    n, T = 65536, 128
+    env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42, ring_depth=2 * T)
+    env.reset_torch()
+    la = torch.full((n, 6), 1.5, dtype=torch.float64, device="cuda")
+    for i in range(10):
+        env.rollout_torch(la, T=T)
+    torch.cuda.current_stream().synchronize()
+    ts = []
+    t_all = time.perf_counter()
+    for i in range(40):
+        t0 = time.perf_counter(); res = env.rollout_torch(la, T=T); ts.append(time.perf_counter() - t0)
+    torch.cuda.current_stream().synchronize()
+    t_all = (time.perf_counter() - t_all) / (40 * T) * 1e6
+    print(f"n={n}: env.rollout_torch(T={T}) {med(ts):8.1f} us per call, {t_all:6.2f} us per step over 40 calls incl. the closing synchronise "
+          f"= {n / t_all * 1e6:.3g} env-steps/s from Python", flush=True)
+    env.close()
+
 if os.environ.get("PROFILE_K4") == "1":
     import cProfile, pstats
     env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=65536, seed=42, num_shards=4, shard_devices=[0] * 4)
