@@ -556,6 +556,81 @@ class ShardedTorchMixin:
     refresh_terminated(ents, hs)  # one launch per device on torch's stream
     return self._result([e[0] for e in ents], range(self._K))
 
+  def rollout_torch(self, action, T=None):
+    """T lockstep steps of every env, ONE launch per shard (ep_pool_rollout), for action sequences
+    already on the GPU: `list_action` float64 `[T, G, 6]` (or `[G, 6]` with T: the same rows every
+    step), optionally "players.env_id" int32 `[T, G]` / `[G]`, G = all envs in order. A shard on the
+    tensors' device reads its columns of them in place (the kernel takes a row stride between
+    steps); for a shard elsewhere they are copied over. Returns T `ShardedResult`s, in stream order
+    on torch's current stream of each shard's device (see `_step_on_streams`). Pools made with
+    `ring_depth >= T`."""
+    import torch
+    from .pool import _flatten_action
+    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    self._need_device_path()
+    if not (self._sync and not self._pending and all(hasattr(s, "_recv_slots_on_stream") for s in self._shards)):
+      raise RuntimeError(f"{type(self).__name__}: rollout_torch needs a sync pool of Dummy shards with nothing outstanding")
+    adict = _flatten_action(action) if isinstance(action, dict) else {"list_action": action}
+    la = adict["list_action"]
+    G, n = self._N, self._n_local
+    if not (isinstance(la, torch.Tensor) and la.is_cuda and la.dtype == torch.float64 and la.is_contiguous()):
+      raise RuntimeError('rollout_torch: "list_action" must be a contiguous float64 CUDA tensor')
+    if la.dim() == 3:
+      T = int(la.shape[0]) if T is None else T
+    if T is None or T < 1 or (la.dim() == 3 and la.shape[0] != T) or tuple(la.shape[-2:]) != (G, la.shape[-1]) or la.dim() not in (2, 3):
+      raise RuntimeError(f"rollout_torch: list_action must be [T, {G}, A] or [{G}, A] with T given, got {tuple(la.shape)}")
+    A = int(la.shape[-1])
+    penv = adict.get("players.env_id")
+    if penv is not None and not (isinstance(penv, torch.Tensor) and penv.is_cuda and penv.dtype == torch.int32 and penv.is_contiguous()
+                                 and tuple(penv.shape) in ((G,), (T, G))):
+      raise RuntimeError(f"rollout_torch: players.env_id must be a contiguous int32 CUDA tensor [{T}, {G}] or [{G}]")
+    if not hasattr(self, "_sh_slots"):
+      self._sh_slots = [dict() for _ in range(self._K)]
+      self._sh_adopted = [None] * self._K
+    if not hasattr(self, "_sh_ids"):
+      self._sh_ids = [torch.from_numpy(self.all_env_ids[r * n:(r + 1) * n].copy()).to(self._shard_dev(r)) for r in range(self._K)]
+    for shard in self._shards:
+      shard._poll_errors()
+    keep, hs = [], []
+    for r, shard in enumerate(self._shards):
+      dev = self._shard_dev(r)
+      h = current_stream_handle(dev)
+      hs.append(h)
+      if self._sh_adopted[r] != h:
+        shard._set_stream(h)
+        self._sh_adopted[r] = h
+        self.__dict__.setdefault("_sh_stream_objs", {})[r] = torch.cuda.current_stream(dev)
+      ids = self._sh_ids[r]
+      if la.device == dev:  # in place: this shard's columns, G rows from one step to the next
+        la_ptr, la_stride = la.data_ptr() + 8 * A * r * n, (G if la.dim() == 3 else 0)
+      else:
+        part = la[..., r * n:(r + 1) * n, :].to(dev).contiguous()
+        keep.append(part)
+        la_ptr, la_stride = part.data_ptr(), (n if la.dim() == 3 else 0)
+      if penv is None:
+        pe_ptr, pe_stride = ids.data_ptr(), 0
+      elif penv.device == dev:
+        pe_ptr, pe_stride = penv.data_ptr() + 4 * r * n, (G if penv.dim() == 2 else 0)
+      else:
+        part = penv[..., r * n:(r + 1) * n].to(dev).contiguous()
+        keep.append(part)
+        pe_ptr, pe_stride = part.data_ptr(), (n if penv.dim() == 2 else 0)
+      shard._rollout(T, [ids.data_ptr(), pe_ptr, la_ptr, ids.data_ptr(), ids.data_ptr()], [n] * 5, [0, pe_stride, la_stride, 0, 0])
+    self._keep_actions = [la, penv, keep]
+    steps = [[] for _ in range(T)]
+    ents_all, hs_all = [], []
+    for r, shard in enumerate(self._shards):
+      dev = self._shard_dev(r)
+      for t, key in enumerate(shard._recv_slots_on_stream(hs[r], T)):
+        ent = self._sh_slots[r].get(key)
+        if ent is None:
+          ent = slot_entry(self, shard._descs_of(t)[0], dev, self._sh_slots[r], key)
+        steps[t].append(ent[0])
+        ents_all.append(ent)
+        hs_all.append(hs[r])
+    refresh_terminated(ents_all, hs_all)
+    return [self._result(parts, range(self._K)) for parts in steps]
+
   def step_torch(self, action, env_id=None, owners=None, stream_ordered=None):
     """step() for a policy on the GPUs. A sync pool stepped as a whole takes one of two forms.
     Shards that each have a GPU to themselves ring their resident servers first

@@ -357,6 +357,51 @@ def test_sharded_device_path_sync_matches_one_oracle(servers, monkeypatch):
   env.close()
 
 
+def test_sharded_rollout_torch_matches_one_oracle():
+  """rollout_torch of a sharded pool (K = 4 pools on one GPU, ring_depth 8): one fused launch per
+  shard reading its columns of the caller's [T, G, 6] / [T, G] tensors in place; every step's parts
+  are that shard's block of ONE big oracle pool stepped T times. Twice, so the shards' rings wrap."""
+  import torch
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  K, n, seed, T = 4, 4096, 6, 6
+  G = K * n
+  env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=G, seed=seed, num_shards=K, shard_devices=[0] * K, ring_depth=8)
+  one = DummyOracle(num_envs=G, seed=seed)
+  ids = np.arange(G, dtype=np.int32)
+  dev = torch.device("cuda", 0)
+  env.reset_torch()
+  one._reset(ids); one._recv()
+  rng = np.random.default_rng(2)
+  for rnd in range(2):
+    pe = ids[None, :] + (rng.random((T, G)) < 0.1).astype(np.int32)
+    lane = rng.integers(0, 4, size=(T, G)).astype(np.float64)
+    la = torch.from_numpy(np.repeat(lane[:, :, None], 6, axis=2)).to(dev)
+    out = env.rollout_torch({"list_action": la, "players.env_id": torch.from_numpy(pe).to(dev)})
+    assert len(out) == T
+    for t in range(T):
+      one._send(dummy_action(ids, players_env_id=pe[t]))
+      want = one._recv()
+      assert len(out[t]) == K
+      for r, (obs, rew, term, trunc, info) in enumerate(out[t]):
+        sl = slice(r * n, (r + 1) * n)
+        ctx = (rnd, t, r)
+        assert _np(obs["raw"]).tobytes() == want[8][sl].tobytes(), ctx
+        assert _np(info["env_id"]).tobytes() == want[0][sl].tobytes() and _np(info["elapsed_step"]).tobytes() == want[2][sl].tobytes(), ctx
+        assert _np(trunc).tobytes() == want[7][sl].tobytes() and _np(term).tobytes() == (want[3] & ~want[7])[sl].tobytes(), ctx
+  # the same rows every step, no players.env_id; then an ordinary step on the same pools
+  la1 = torch.full((G, 6), 2.0, dtype=torch.float64, device=dev)
+  out = env.rollout_torch(la1, T=3)
+  for t in range(3):
+    one._send(dummy_action(ids))
+    want = one._recv()
+    assert _np(out[t].cat()[0]["raw"]).tobytes() == want[8].tobytes(), t
+  res = env.step_torch({"list_action": la1})
+  one._send(dummy_action(ids))
+  assert _np(res.cat()[0]["raw"]).tobytes() == one._recv()[8].tobytes()
+  env.close()
+
+
 def test_sharded_device_path_async_sets_by_env():
   """Async sharded pool on the device path: recv_torch hands out K shard batches from whichever
   shards are ready (`owners`), send_torch routes per-part actions back; per env the rows equal one
