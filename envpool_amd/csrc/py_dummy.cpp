@@ -407,6 +407,27 @@ struct DummyPool {
 
 }  // namespace
 
+// ep_terminated_many with its argument arrays built once: a front-end sees the same ring slots come
+// round again, so "terminated of THESE batches" is a handful of fixed plans launched again and again.
+struct TermPlan {
+  std::vector<const void*> done, trunc;
+  std::vector<void*> out;
+  std::vector<int64_t> n;
+  int device;
+  TermPlan(const std::vector<uintptr_t>& d, const std::vector<uintptr_t>& t, const std::vector<uintptr_t>& o, const std::vector<int64_t>& nn, int dev)
+      : n(nn), device(dev) {
+    if (d.size() != t.size() || d.size() != o.size() || d.size() != nn.size()) throw std::invalid_argument("TermPlan: lists of different lengths");
+    for (size_t i = 0; i < d.size(); ++i) {
+      done.push_back(reinterpret_cast<const void*>(d[i]));
+      trunc.push_back(reinterpret_cast<const void*>(t[i]));
+      out.push_back(reinterpret_cast<void*>(o[i]));
+    }
+  }
+  void launch(uintptr_t stream) const {
+    epy::check(ep_terminated_many((int32_t)done.size(), done.data(), trunc.data(), out.data(), n.data(), device, reinterpret_cast<void*>(stream)));
+  }
+};
+
 PYBIND11_MODULE(dummy_envpool, m) {
   py::object abc_meta = py::module_::import("abc").attr("ABCMeta");  // py_envpool.h:261
   py::class_<DummySpec>(m, "_DummyEnvSpec", py::metaclass(abc_meta))
@@ -452,6 +473,9 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_stream", &DummyPool::stream)
       .def("_handle", &DummyPool::handle)
       .def("close", &DummyPool::close);
+  py::class_<TermPlan>(m, "TermPlan")
+      .def(py::init<const std::vector<uintptr_t>&, const std::vector<uintptr_t>&, const std::vector<uintptr_t>&, const std::vector<int64_t>&, int>())
+      .def("launch", &TermPlan::launch);
   m.def("device_count", []() { return ep_device_count(); });
   m.def("stream_synchronize", [](int device, uintptr_t stream) {
     int rc;

@@ -8,6 +8,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from .spec import check_unique
+from .streamstep import current_stream_handle, refresh_terminated, slot_entry
 from .tree import Layout
 
 try:  # dm_env is optional; the local TimeStep has the same fields and helpers
@@ -73,6 +74,15 @@ class EnvPoolFrontEnd:
   @property
   def config(self) -> Dict[str, Any]:
     return dict(zip(self._spec._config_keys, self._spec._config_values))
+
+  @property
+  def _cfg(self) -> Dict[str, Any]:
+    """`config` built once, for the per-step paths (the property above makes a new dict from the
+    spec's tuples on every access, several microseconds each)."""
+    c = self.__dict__.get("_cfg_cached")
+    if c is None:
+      c = self.__dict__["_cfg_cached"] = self.config
+    return c
 
   @property
   def all_env_ids(self) -> np.ndarray:
@@ -153,7 +163,7 @@ class EnvPoolFrontEnd:
     if env_id is None:
       env_id = self.all_env_ids
     self._reset(env_id)
-    return self.recv(reset=True, return_info=self.config["gym_reset_return_info"])
+    return self.recv(reset=True, return_info=self._cfg["gym_reset_return_info"])
 
   def xla(self):
     raise RuntimeError("XLA is disabled (jax is not part of this build).")
@@ -230,7 +240,7 @@ class EnvPoolFrontEnd:
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
     keys = self._spec._action_keys
     if not hasattr(self, "_torch_dev"):
-      self._torch_dev = torch.device("cuda", self.config.get("device_id", 0))
+      self._torch_dev = torch.device("cuda", self._cfg.get("device_id", 0))
       self._torch_views = {}
     dev = self._torch_dev
     # the usual loop passes the same tensors every step: their pointers and sizes are kept
@@ -276,13 +286,12 @@ class EnvPoolFrontEnd:
         ptrs.append(t.data_ptr())
         dims.append(int(t.shape[0]))
       self._step_torch_cached = None if (converted or sig is None) else (sig, ptrs, dims, keep)
-    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
     if not hasattr(self, "_slot_results"):
       self._slot_results = {}
     h = current_stream_handle(dev)
     self._keep_actions = keep
-    if stream_ordered and hasattr(self, "_send_on_stream") and dims[0] == self.config["num_envs"] == self.config["batch_size"] \
-        and self.config["max_num_players"] == 1:
+    cfg = self._cfg
+    if stream_ordered and hasattr(self, "_send_on_stream") and dims[0] == cfg["num_envs"] == cfg["batch_size"] and cfg["max_num_players"] == 1:
       self._poll_errors()  # what earlier stream-ordered steps have flagged by now
       if getattr(self, "_adopted_stream", None) != h:
         self._set_stream(h)
@@ -298,7 +307,7 @@ class EnvPoolFrontEnd:
       from ..dummy.dummy_envpool import stream_synchronize
       stream_synchronize(dev.index, h)
       descs, nrows, _ = self._step_device(ptrs, dims)
-      if self.config["max_num_players"] > 1:  # (the player rows of a slot change from step to step: nothing to keep)
+      if cfg["max_num_players"] > 1:  # (the player rows of a slot change from step to step: nothing to keep)
         return self._torch_out(descs, False)
       key = (descs[0][0], nrows)
       ent = self._slot_results.get(key)
@@ -320,7 +329,6 @@ class EnvPoolFrontEnd:
     surface at a later call or `_sync()`). This is the path bench.py times: 1.4 us per
     65 536-env step instead of 4.5 (one launch per step) or 6.7 (blocking)."""
     import torch
-    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
     if not hasattr(self, "_rollout") or not hasattr(self, "_recv_slots_on_stream"):
       raise RuntimeError(f"{type(self).__name__} has no fused rollout")
     if not hasattr(self, "_torch_dev"):
@@ -331,15 +339,15 @@ class EnvPoolFrontEnd:
     la = adict["list_action"]
     if not (isinstance(la, torch.Tensor) and la.is_cuda):
       raise RuntimeError('rollout_torch: "list_action" must be a CUDA tensor')
-    n = self.config["num_envs"]
+    n = self._cfg["num_envs"]
     if la.dim() == 3:
       T = int(la.shape[0]) if T is None else T
       if la.shape[0] != T:
         raise RuntimeError(f"rollout_torch: list_action has {la.shape[0]} steps, T = {T}")
     if T is None or T < 1:
       raise RuntimeError("rollout_torch: give T with a [N, 6] list_action")
-    if tuple(la.shape[-2:]) != (n, self.config["action_num"]):
-      raise RuntimeError(f"rollout_torch: list_action must end in [{n}, {self.config['action_num']}], got {tuple(la.shape)}")
+    if tuple(la.shape[-2:]) != (n, self._cfg["action_num"]):
+      raise RuntimeError(f"rollout_torch: list_action must end in [{n}, {self._cfg['action_num']}], got {tuple(la.shape)}")
     if la.dtype != torch.float64 or not la.is_contiguous():
       la = la.to(torch.float64).contiguous()
     if not hasattr(self, "_all_env_ids_torch"):

@@ -33,15 +33,35 @@ def slot_entry(front, descs, dev, cache, key):
   return ent
 
 
+_PLANS = {}
+
+
 def refresh_terminated(ents, handles):
-  """terminated = done & ~trunc for every entry that has one, on stream `handles[i]` of its device."""
-  from ..dummy.dummy_envpool import terminated_many
+  """terminated = done & ~trunc for every entry that has one, on stream `handles[i]` of its device:
+  one launch of ep_terminated_many per (device, stream). The argument arrays of a launch are kept as
+  a plan keyed by the addresses themselves (the same slots come round again)."""
+  if len(ents) == 1:  # the unsharded step: the plan sits in the entry
+    e = ents[0]
+    if e[1] is not None:
+      if len(e) < 3:
+        from ..dummy.dummy_envpool import TermPlan
+        p = e[1]
+        e.append(TermPlan([p[0]], [p[1]], [p[2]], [p[3]], p[4]))
+      e[2].launch(handles[0])
+    return
   by_dev = {}
   for e, h in zip(ents, handles):
     if e[1] is not None:
       by_dev.setdefault((e[1][4], h), []).append(e[1])
   for (dev_index, h), ps in by_dev.items():
-    terminated_many([p[0] for p in ps], [p[1] for p in ps], [p[2] for p in ps], [p[3] for p in ps], dev_index, h)
+    key = tuple(ps)
+    plan = _PLANS.get(key)
+    if plan is None:
+      from ..dummy.dummy_envpool import TermPlan
+      if len(_PLANS) > 4096:
+        _PLANS.clear()
+      plan = _PLANS[key] = TermPlan([p[0] for p in ps], [p[1] for p in ps], [p[2] for p in ps], [p[3] for p in ps], dev_index)
+    plan.launch(h)
 
 
 def current_stream_handle(dev):
