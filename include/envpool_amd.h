@@ -244,7 +244,9 @@ int ep_pool_step_on_stream(ep_pool* pool, void* stream, int32_t n_arrays, const 
 /* The send half of it alone: ep_pool_send(EP_MEM_DEVICE) ordered behind everything submitted to
  * `stream` so far. A caller that steps several pools from one stream sends to ALL of them first and
  * only then receives (ep_pool_recv_on_stream): each pool then waits for the actions alone, not for the
- * rows of the pools before it, and their kernels run side by side. */
+ * rows of the pools before it, and their kernels run side by side. No counterpart in the reference
+ * (AsyncEnvPool::Send, async_envpool.h:162-164, takes host arrays and returns at once: this is that
+ * call for arrays a stream is still writing). */
 int ep_pool_send_on_stream(ep_pool* pool, void* stream, int32_t n_arrays, const void* const* arrays,
                            const int64_t* leading_dims);
 
@@ -367,7 +369,8 @@ int ep_terminated_many(int32_t k, const void* const* done, const void* const* tr
                        const int64_t* n, int32_t device, void* stream);
 /* hipStreamSynchronize(stream) on `device` (-1: the current one), for front-ends that hold a raw
  * stream handle and must see the producer of the action arrays finished before a blocking
- * ep_pool_step (which reads them from a resident kernel, outside any stream's order). */
+ * ep_pool_step (which reads them from a resident kernel, outside any stream's order). No
+ * counterpart in the reference. */
 int ep_stream_synchronize(int32_t device, void* stream);
 int32_t ep_device_count(void);
 const char* ep_last_error(void); /* thread-local text of the last failure */
