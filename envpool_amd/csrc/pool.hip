@@ -1537,7 +1537,11 @@ int ep_pool_set_stream(ep_pool* p, void* stream, int32_t own) {
   if ((rc = server_stop(p))) return rc;
   // everything enqueued so far finishes on the stream it was enqueued on: launches, completion
   // events and timing events all refer to that stream
-  if ((rc = sync_stream_unlocked(p, &lk))) return rc;
+  // (the lock is released around the wait: whatever another thread enqueued meanwhile is waited for too)
+  for (uint64_t upto = ~0ull; upto != p->launch_seq;) {
+    upto = p->launch_seq;
+    if ((rc = sync_stream_unlocked(p, &lk))) return rc;
+  }
   if ((rc = drain_timed(p))) return rc;
   if (p->step_mode != 0) return fail(EP_ERR_INVALID, "ep_pool_set_stream raced with ep_pool_step_begin");
   p->stream = next;
