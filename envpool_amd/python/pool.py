@@ -216,25 +216,31 @@ class EnvPoolFrontEnd:
       t = self._torch_views[key] = as_torch(desc, self._torch_dev)
     return t
 
-  def step_torch(self, action, env_id=None, stream_ordered: bool = False):
+  def step_torch(self, action, env_id=None, stream_ordered: Optional[bool] = None):
     """step() for a policy that lives on the GPU: `action` is a torch CUDA tensor (the last action
     key) or a dict of them in the shapes step() takes, `env_id` an int32 CUDA tensor or None for all
-    envs in order. Returns what step() returns, as torch tensors aliasing the device ring. A sync
-    pool stepped as a whole takes no kernel launch (ep_pool_step, the pool's resident kernel), as
-    long as the action tensors keep their addresses: pass contiguous int32 / float64 tensors and
-    reuse them (a tensor that needs a dtype or layout conversion is copied into a staging tensor the
-    pool keeps, so the addresses the resident kernel is bound to stay the same either way).
-    While that kernel sits on the GPU a device-wide wait (torch.cuda.synchronize()) between two
-    steps has to wait for it to leave - the pool's watchdog bounds that to about ten step gaps,
-    200 us at least, and falls back to launching per step for callers that keep doing it; use
-    torch.cuda.current_stream().synchronize() instead (include/envpool_amd.h, ep_pool_step).
+    envs in order. Returns what step() returns, as torch tensors aliasing the device ring (valid
+    until `ring_depth - 1` further batches have been received).
 
-    stream_ordered=True (sync single-player pools stepped as a whole): the step is ENQUEUED on
-    torch's current stream, which the pool adopts as its step stream (ep_pool_set_stream), and the
-    call returns at once - one kernel launch, no host wait, no resident kernel; the result is valid
-    for work queued on that stream afterwards (reading it on the host synchronises the stream like
-    any torch tensor), and a step's error (list_action self-check) surfaces at a later step or at
-    `_sync()` instead of at the step itself."""
+    A sync single-player pool stepped as a whole is stepped IN STREAM ORDER by default
+    (stream_ordered=None or True): the step is enqueued on torch's current stream, which the pool
+    adopts as its step stream (ep_pool_set_stream + ep_pool_step_on_stream), and the call returns at
+    once - one kernel launch, no host wait (10 us per call at 65 536 envs). The result is valid for
+    work queued on that stream afterwards, like the output of any torch op (reading it on the host
+    synchronises the stream), and a step's error (the list_action self-check) surfaces at a later
+    step or at `_sync()` rather than at the step itself, as CUDA errors do in torch.
+
+    stream_ordered=False is the BLOCKING form (ep_pool_step, 21 us): the rows are complete and
+    errors are raised when the call returns. It takes no kernel launch (the pool's resident kernel
+    answers a doorbell) as long as the action tensors keep their addresses: pass contiguous int32 /
+    float64 tensors and reuse them (a tensor that needs a dtype or layout conversion is copied into
+    a staging tensor the pool keeps, so the addresses the resident kernel is bound to stay the same
+    either way). While that kernel sits on the GPU a device-wide wait (torch.cuda.synchronize())
+    between two steps has to wait for it to leave - the pool's watchdog bounds that to about ten
+    step gaps, 200 us at least, and falls back to launching per step for callers that keep doing
+    it; use torch.cuda.current_stream().synchronize() instead (include/envpool_amd.h,
+    ep_pool_step). Every other case (async pools, partial sends, several players) is a send and a
+    blocking recv."""
     import torch
     if not hasattr(self, "_step_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
@@ -291,7 +297,8 @@ class EnvPoolFrontEnd:
     h = current_stream_handle(dev)
     self._keep_actions = keep
     cfg = self._cfg
-    if stream_ordered and hasattr(self, "_send_on_stream") and dims[0] == cfg["num_envs"] == cfg["batch_size"] and cfg["max_num_players"] == 1:
+    if stream_ordered is not False and hasattr(self, "_send_on_stream") and dims[0] == cfg["num_envs"] == cfg["batch_size"] \
+        and cfg["max_num_players"] == 1:
       self._poll_errors()  # what earlier stream-ordered steps have flagged by now
       if getattr(self, "_adopted_stream", None) != h:
         self._set_stream(h)

@@ -632,20 +632,20 @@ class ShardedTorchMixin:
     return [self._result(parts, range(self._K)) for parts in steps]
 
   def step_torch(self, action, env_id=None, owners=None, stream_ordered=None):
-    """step() for a policy on the GPUs. A sync pool stepped as a whole takes one of two forms.
-    Shards that each have a GPU to themselves ring their resident servers first
-    (ep_pool_step_begin) and then wait for each (ep_pool_step_end): side by side, no kernel launch,
-    blocking like the unsharded step_torch. Shards that SHARE a device cannot each keep a resident
-    kernel there (include/envpool_amd.h, ep_pool_step): they step in stream order
-    (ep_pool_step_on_stream) - the result is valid for work queued on torch's current stream, the
-    host waits for nothing, and a step's error (list_action self-check) surfaces at a later
-    step_torch or `_sync_all()` instead of this one. `stream_ordered` picks the form explicitly."""
+    """step() for a policy on the GPUs. A sync pool stepped as a whole takes one of two forms. The
+    default (stream_ordered None or True) is the step IN STREAM ORDER, as for an unsharded pool's
+    step_torch: every shard adopts torch's current stream of its device and its step kernel is
+    enqueued there (ep_pool_step_on_stream) - the result is valid for work queued on those streams,
+    the host waits for nothing, and a step's error (list_action self-check) surfaces at a later
+    step_torch or `_sync_all()` instead of this one. stream_ordered=False is the BLOCKING form:
+    the shards' resident servers are rung first (ep_pool_step_begin) and then waited for one by one
+    (ep_pool_step_end) - side by side and without a kernel launch where every shard has a GPU to
+    itself; shards that SHARE a device cannot each keep a resident kernel there
+    (include/envpool_amd.h, ep_pool_step) and pay a launch and a wait each."""
     import torch
     self._need_device_path()
     if self._sync and env_id is None and not self._pending and all(hasattr(s, "_step_begin") for s in self._shards):
-      if stream_ordered is None:
-        stream_ordered = len(set(self._devices)) < self._K
-      stream_ordered = bool(stream_ordered) and self._P == 1 and all(hasattr(s, "_send_on_stream") for s in self._shards)
+      stream_ordered = stream_ordered is not False and self._P == 1 and all(hasattr(s, "_send_on_stream") for s in self._shards)
       # the usual loop passes the same tensors every step: their per-shard slices (pointers, sizes) are kept
       flat = action.items() if isinstance(action, dict) else ((None, action),)
       sig = tuple((k, v.data_ptr(), tuple(v.shape), v.dtype, v.device) if isinstance(v, torch.Tensor) else (k, id(v)) for k, v in flat)

@@ -381,7 +381,7 @@ def test_step_torch_stream_ordered_front_end():
   with pytest.raises(RuntimeError, match="self-check"):
     env.step_torch(act, stream_ordered=True)
   # the blocking form and the numpy boundary still work on the same pool (its stream stays adopted)
-  res = env.step_torch(act)
+  res = env.step_torch(act, stream_ordered=False)
   one._send(dummy_action(ids, players_env_id=pe))
   check(res, one._recv(), "blocking step afterwards")
   a = dummy_action(ids)

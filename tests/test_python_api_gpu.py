@@ -113,11 +113,12 @@ def test_device_views_and_torch_interop():
     o._send(dummy_action(ids))
 
 
-@pytest.mark.parametrize("n", [512, 300])
-def test_step_torch_front_end(n):
+@pytest.mark.parametrize("n,blocking", [(512, True), (300, True), (512, False), (300, False)])
+def test_step_torch_front_end(n, blocking):
   """step_torch / reset_torch: a policy on the GPU steps the pool with torch tensors and gets torch
-  tensors back (n = 512 takes the resident-kernel path of ep_pool_step, n = 300 the launch path);
-  same structure as step(), values equal to the oracle's."""
+  tensors back; same structure as step(), values equal to the oracle's. blocking: stream_ordered=False
+  (n = 512 takes the resident-kernel path of ep_pool_step, n = 300 the launch path); otherwise the
+  default, the step in stream order on torch's current stream."""
   import torch
   import envpool_amd
   from oracle.dummy_oracle import DummyOracle
@@ -130,7 +131,7 @@ def test_step_torch_front_end(n):
   assert obs["raw"].is_cuda and obs["raw"].cpu().numpy().tobytes() == w[8].tobytes()
   la = torch.full((n, 6), 1.5, dtype=torch.float64, device=dev)
   for t in range(12):
-    obs, rew, term, trunc, info = env.step_torch({"list_action": la})
+    obs, rew, term, trunc, info = env.step_torch({"list_action": la}, **({"stream_ordered": False} if blocking else {}))
     o._send(dummy_action(ids)); w = o._recv()
     assert info["env_id"].cpu().numpy().tobytes() == w[0].tobytes()
     assert info["elapsed_step"].cpu().numpy().tobytes() == w[2].tobytes(), t
@@ -184,7 +185,7 @@ def test_rollout_torch_front_end(n):
       check(out[t], o._recv(), f"same rows, round {rnd}, t={t}")
   # a step in stream order and a blocking step on the same pool afterwards
   check(env.step_torch({"list_action": la[0]}, stream_ordered=True), (o._send(dummy_action(ids)), o._recv())[1], "stream-ordered step after")
-  check(env.step_torch({"list_action": la[0]}), (o._send(dummy_action(ids)), o._recv())[1], "blocking step after")
+  check(env.step_torch({"list_action": la[0]}, stream_ordered=False), (o._send(dummy_action(ids)), o._recv())[1], "blocking step after")
   with pytest.raises(Exception):
     env.rollout_torch(la[0], T=17)  # more steps than ring slots
   env.close()

@@ -37,17 +37,18 @@ for n, k in ((65536, 1), (65536, 4), (65536, 8), (524288, 8)) if os.environ.get(
     env.reset_torch()
     la = torch.full((n, 6), 1.5, dtype=torch.float64, device="cuda")
     ts, tc = [], []
+    main = {"stream_ordered": False} if k == 1 else {}  # (unsharded: the blocking form first, the default in brackets)
     for i in range(200):
-        env.step_torch({"list_action": la})
+        env.step_torch({"list_action": la}, **main)
     torch.cuda.current_stream().synchronize()
     t_all = time.perf_counter()
     for i in range(1000):
-        t0 = time.perf_counter(); res = env.step_torch({"list_action": la}); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); res = env.step_torch({"list_action": la}, **main); ts.append(time.perf_counter() - t0)
     torch.cuda.current_stream().synchronize()
     t_all = (time.perf_counter() - t_all) / 1000 * 1e6
     # (median of the calls, and 1000 calls + one closing stream synchronise over 1000: the same for the
     # blocking forms; for the stream-ordered form the second one is the figure that cannot hide work)
-    line = f"n={n} shards={k}: env.step_torch {med(ts):8.1f} us  ({t_all:6.1f} us per step over 1000 steps incl. the closing synchronise)"
+    line = f"n={n} shards={k}: env.step_torch{'(stream_ordered=False)' if k == 1 else ''} {med(ts):8.1f} us  ({t_all:6.1f} us per step over 1000 steps incl. the closing synchronise)"
     if k == 1:
         for i in range(200):
             env.step_torch({"list_action": la}, stream_ordered=True)
@@ -58,7 +59,7 @@ for n, k in ((65536, 1), (65536, 4), (65536, 8), (524288, 8)) if os.environ.get(
             t0 = time.perf_counter(); env.step_torch({"list_action": la}, stream_ordered=True); ts2.append(time.perf_counter() - t0)
         torch.cuda.current_stream().synchronize()
         t2 = (time.perf_counter() - t2) / 1000 * 1e6
-        line += f"   [stream_ordered=True: {med(ts2):6.1f} us per call, {t2:6.1f} us per step over 1000 steps incl. the closing synchronise]"
+        line += f"   [the default, in stream order: {med(ts2):6.1f} us per call, {t2:6.1f} us per step over 1000 steps incl. the closing synchronise]"
     if k > 1:
         ts2 = []
         for i in range(600):
