@@ -44,7 +44,7 @@ SYMBOLS = [
   "ep_pool_stream", "ep_pool_set_timing", "ep_pool_kernel_time_us", "ep_device_count",
   "ep_last_error", "ep_version", "ep_dummy_send_noalloc", "ep_pool_step", "ep_pool_last_rollout_kernel",
   "ep_pool_step_begin", "ep_pool_step_end", "ep_pool_server_stats", "ep_pool_server_trace", "ep_pool_recv_many_on_stream",
-  "ep_pool_step_on_stream", "ep_pool_send_on_stream", "ep_pool_poll_errors", "ep_pool_set_stream", "ep_terminated_many", "ep_stream_synchronize",
+  "ep_pool_step_on_stream", "ep_pool_send_on_stream", "ep_pool_poll_errors", "ep_pool_set_stream", "ep_terminated_many", "ep_stream_synchronize", "ep_pool_terminated_of",
 ]
 
 _bound = None
@@ -71,6 +71,7 @@ def lib():
     L.ep_pool_poll_errors.argtypes = [vp]
     L.ep_pool_set_stream.argtypes = [vp, vp, i32]
     L.ep_stream_synchronize.argtypes = [i32, vp]
+    L.ep_pool_terminated_of.argtypes = [vp, C.POINTER(Batch), C.POINTER(vp)]
     L.ep_terminated_many.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp]
     L.ep_pool_send_on_stream.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(i64)]
     L.ep_pool_server_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(i64)]

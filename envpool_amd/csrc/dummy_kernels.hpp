@@ -280,6 +280,7 @@ struct StepArgs {
   int32_t row0;
   int32_t force_reset;
   int32_t la_bit0;
+  uint8_t* term;  // [B] or null: gymnasium's terminated = done & ~trunc of each row, beside the slot (ep_pool_terminated_of)
 };
 
 // DEV: the device-memory step (not a reset, list_action rows on the device, duplicate stamps on):
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
     st.discount[tid] = o.done ? 0.f : 1.f;  // env.h:202
     st.done[tid] = o.done;
     st.trunc[tid] = o.trunc;
+    if (a.term) a.term[(int64_t)a.row0 + i] = (uint8_t)(o.done & (o.trunc ^ 1));  // (64 lanes, 64 consecutive bytes)
   }
   __syncthreads();
   write_tiles_sp<S_CT>(a.slot, (int64_t)a.row0 + (int64_t)blockIdx.x * kBlock, blk_valid, a.pc.S, st, tid);

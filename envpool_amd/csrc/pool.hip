@@ -58,6 +58,7 @@ struct SlotHost {
   uint64_t launch_id = 0;  // id of the last launch that wrote this slot
   int mp_word = -1;        // multi-player pools: index of the player-total word of this batch
   void* host_blk = nullptr;  // direct host mode: the kernels wrote this batch straight into a pinned block, not the ring
+  bool term_ok = false;      // every row so far came from a step kernel that also wrote d_term (ep_pool_terminated_of)
 };
 
 }  // namespace
@@ -73,6 +74,9 @@ struct ep_pool {
   hipStream_t own_stream = nullptr;  // the stream the pool created; `stream` is another one while adopted (ep_pool_set_stream)
   // device state
   epk::EnvRec* d_env = nullptr;
+  uint8_t* d_term = nullptr;            // [Q][term_stride]: terminated = done & ~trunc of the rows of each ring slot (step kernels)
+  size_t term_stride = 0;
+  std::vector<uint64_t> slot_term_seq;  // [Q]: seq + 1 of the received batch whose d_term rows are valid, else 0
   epk::StatPtrs stats{};
   char* d_ring = nullptr;
   size_t slot_stride = 0;
@@ -577,6 +581,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.n = n;
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
+  a.term = out_base ? nullptr : p->d_term + (size_t)slot * p->term_stride;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
   const bool dev = !force_reset && d_la && a.stamp && !p->force_generic;  // (see dummy_step_sp)
   if (p->S == 10 && dev)
@@ -660,6 +665,7 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
                    d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0, force_reset,
                    !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0);
     if (rc != EP_OK) { abandon_launch(p, le); break; }
+    sh.term_ok = (sh.has_work ? sh.term_ok : true) && out_base == nullptr;
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
@@ -1031,6 +1037,10 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
     }
   }
   p->slots.resize(p->Q);
+  p->term_stride = ((size_t)p->B + 255) & ~(size_t)255;
+  HIP_TRY(hipMalloc((void**)&p->d_term, p->term_stride * (size_t)p->Q));
+  HIP_TRY(hipMemsetAsync(p->d_term, 0, p->term_stride * (size_t)p->Q, p->stream));
+  p->slot_term_seq.assign((size_t)p->Q, 0);
   HIP_TRY(hipEventCreateWithFlags(&p->stats_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->consumer_ev, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->recv_ev, hipEventDisableTiming));
@@ -1075,6 +1085,7 @@ int ep_pool_destroy(ep_pool* p) {
   for (auto e : p->stage_copied) (void)hipEventDestroy(e);
   (void)hipFree(p->d_ring);
   (void)hipFree(p->d_env);
+  (void)hipFree(p->d_term);
   (void)hipFree(p->d_stamp);
   (void)hipFree(p->stats.ep_return);
   (void)hipFree(p->stats.fin_return);
@@ -1318,6 +1329,7 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
     sh.shared_off += p->B;
     sh.written.emplace_back(0, p->B);
     sh.has_work = true;
+    sh.term_ok = false;  // (the rollout kernels do not write d_term)
     sh.launch_id = lid;
   }
   end_launch(p, le, lid);
@@ -1403,6 +1415,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
         char* base = p->d_ring + (size_t)slot * p->slot_stride + p->key_off[k];
         HIP_TRY(hipMemsetAsync(base + (size_t)a * p->key_rowbytes[k], 0, (size_t)(b - a) * p->key_rowbytes[k], p->stream));
       }
+      HIP_TRY(hipMemsetAsync(p->d_term + (size_t)slot * p->term_stride + (size_t)a, 0, (size_t)(b - a), p->stream));
       any = true;
       return EP_OK;
     };
@@ -1490,6 +1503,8 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
   sh.written.clear();
   sh.has_work = false;
   sh.mp_word = -1;
+  p->slot_term_seq[slot] = (sh.term_ok && mem == EP_MEM_DEVICE && p->P == 1) ? out->seq + 1 : 0;
+  sh.term_ok = false;
   if (p->is_sync) p->stepping_env_num -= nrows;
   return status;
 }
@@ -1573,6 +1588,21 @@ int ep_pool_step_on_stream(ep_pool* p, void* stream, int32_t n_arrays, const voi
   int rc = ep_pool_send_on_stream(p, stream, n_arrays, arrays, leading_dims);
   if (rc) return rc;
   return ep_pool_recv_on_stream(p, stream, out);
+}
+
+int ep_pool_terminated_of(ep_pool* p, const ep_batch* b, void** term) {
+  if (!p || !b || !term) return fail(EP_ERR_INVALID, "null argument");
+  *term = nullptr;
+  std::lock_guard<std::mutex> lk(p->mu);
+  const char* first = (const char*)b->arrays[0].data;
+  if (b->mem != EP_MEM_DEVICE || !first || first < p->d_ring || first >= p->d_ring + p->slot_stride * (size_t)p->Q)
+    return fail(EP_ERR_INVALID, "not a batch of device views of this pool");
+  const size_t slot = (size_t)(first - p->d_ring) / p->slot_stride;
+  if (p->slot_term_seq[slot] != b->seq + 1)
+    return fail(EP_ERR_INVALID, "no terminated array for this batch (its rows came from a rollout, the resident step kernel, "
+                                "host memory or a multi-player pool, or the slot has been handed out again): use ep_terminated_many");
+  *term = p->d_term + slot * p->term_stride;
+  return EP_OK;
 }
 
 int ep_pool_poll_errors(ep_pool* p) {
@@ -1730,6 +1760,7 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
       if (p->step_warm) { p->idle_streak = 0; p->server_fresh = false; }
       const uint64_t bi = p->step_bi;
       const int slot = (int)(bi % (uint64_t)p->Q);
+      p->slot_term_seq[slot] = 0;  // (the resident kernel does not write d_term)
       const int status = status_of_err_bits(take_err_bits(p, err_index(p, bi)), "step");
       p->alloc_count += (uint64_t)p->B;  // one whole batch allocated ...
       p->done_ptr += 1;                  // ... and received

@@ -311,7 +311,10 @@ struct DummyPool {
   }
   py::tuple recv_slot_on_stream(uintptr_t stream) {
     epy::check(ep_pool_recv_on_stream(pool, reinterpret_cast<void*>(stream), &last_batch));
-    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows);
+    // third element: the batch's `terminated` array where its step kernels wrote one (ep_pool_terminated_of), else 0
+    void* term = nullptr;
+    if (ep_pool_terminated_of(pool, &last_batch, &term) != EP_OK) term = nullptr;
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows, reinterpret_cast<uintptr_t>(term));
   }
   // ep_pool_recv_many_on_stream: the T batches of a rollout as (first address, rows) each; a
   // front-end asks _descs_of(i) only for ring slots it has not seen yet.

@@ -19,7 +19,13 @@ def slot_entry(front, descs, dev, cache, key):
   vals = [None if d is None else as_torch(d, dev) for d in descs]
   tmpl, idx, done, trunc = front._to_slot(vals)
   ent = [tmpl, None]
-  if idx is not None:
+  term_ptr = key[2] if len(key) > 2 else 0
+  if idx is not None and term_ptr:
+    # the step kernels wrote `terminated` beside this slot (ep_pool_terminated_of): a view, no launch
+    lst = list(tmpl)
+    lst[idx] = as_torch((term_ptr, tuple(done.shape), "|b1"), dev)
+    ent = [tuple(lst), None]
+  elif idx is not None:
     if not (type(tmpl) is tuple and done.dtype == torch.bool and trunc.dtype == torch.bool and done.is_contiguous()
             and trunc.is_contiguous()):
       raise RuntimeError("stream-ordered step: unexpected result layout")

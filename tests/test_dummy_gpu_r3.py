@@ -277,7 +277,13 @@ def test_step_on_stream_no_host_wait_matches_oracle():
           store[k] = torch.empty((steps,) + tuple(v.shape), dtype=v.dtype, device=dev)
         store[k][t].copy_(v)
   assert len(views) == 4 * len(keys)  # the ring's four slots, again and again
+  # the last batch's `terminated`, written by its step kernel beside the slot: no launch, a pointer
+  term = C.c_void_p()
+  assert L.ep_pool_terminated_of(g.handle, C.byref(b), C.byref(term)) == 0, L.ep_last_error()
+  t_term = interop.as_torch((term.value, (n,), "|b1"), device=dev)
   side.synchronize()
+  last = {k: views[b.arrays[k].data].cpu().numpy() for k in (3, 7)}
+  assert t_term.cpu().numpy().tobytes() == (last[3] & ~last[7]).tobytes()
   assert L.ep_pool_poll_errors(g.handle) == 0, L.ep_last_error()
   host = {k: store[k].cpu().numpy() for k in keys}
   for t in range(steps):
@@ -316,6 +322,14 @@ def test_step_on_stream_no_host_wait_matches_oracle():
     o._send([ids, penv_all[t], np.repeat(lane_all[t][:, None], 6, axis=1), ids * 0, ids * 0])
     want = o._recv()
     assert_batches_equal([None if k == 9 else host[k][t] for k in range(12)], want, f"adopted stream, step {t}")
+  # batches written by the resident kernel of ep_pool_step or by a rollout carry no such array
+  assert L.ep_pool_set_stream(g.handle, None, 1) == 0, L.ep_last_error()
+  t_penv.copy_(t_ids); torch.cuda.synchronize()
+  assert L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b)) == 0, L.ep_last_error()
+  o._send([ids, ids, np.repeat(lane_all[59][:, None], 6, axis=1), ids * 0, ids * 0]); o._recv()
+  served = g.server_stats()[2]
+  rc = L.ep_pool_terminated_of(g.handle, C.byref(b), C.byref(term))
+  assert (rc == capi.EP_ERR_INVALID and term.value is None) if served else rc == 0
   # back on its own stream the blocking calls are what they were
   assert L.ep_pool_set_stream(g.handle, None, 1) == 0, L.ep_last_error()
   assert L.ep_pool_stream(g.handle) != side.cuda_stream

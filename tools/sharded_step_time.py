@@ -30,7 +30,11 @@ for n, b, k in ((8192, 4096, 1), (8192, 4096, 8)) if NUMPY else ():
 
 # the device path (round 3): CUDA tensors in, per-shard views of the rings out, nothing crosses PCIe;
 # a whole-pool step rings every shard's resident server and then waits for each
+import gc
 import torch
+# (a full garbage collection of a process that has imported torch takes ~40 ms, and the per-step result
+# tuples are enough garbage to trigger one now and then: keep what exists now out of the collector's way)
+gc.collect(); gc.freeze()
 for n, k in ((65536, 1), (65536, 4), (65536, 8), (524288, 8)) if os.environ.get('ONLY_K4') != '1' else ((65536, 4),):
     kw = dict(num_shards=k, shard_devices=[0] * k) if k > 1 else {}
     env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42, **kw)

@@ -17,6 +17,8 @@ env = envpool_amd.make("Dummy-v0", "gymnasium", num_envs=n, seed=42)
 env.reset_torch()
 la = torch.full((n, 6), 1.5, dtype=torch.float64, device="cuda")
 act = {"list_action": la}
+import gc
+gc.collect(); gc.freeze()  # (a full collection of a torch process is a ~40 ms pause; see tools/sharded_step_time.py)
 for so in (True, False, True):
   for i in range(4000):  # (long enough for the clocks to come up: a cold GPU runs the first milliseconds slowly)
     env.step_torch(act, stream_ordered=so)
