@@ -77,6 +77,8 @@ struct ServerArgs {
   int32_t two_level_join;         // 1: shard counters, then one global counter whose last arriver writes done[0] (round 2's join)
   unsigned long long* trace;      // diagnostic (EP_SERVER_TRACE=1), else null: per workgroup 4 timestamps of its last
                                   // step (100 MHz wall clock): doorbell seen, rows staged, stores drained, counted in
+  uint8_t* term;                  // [depth][term_stride]: terminated = done & ~trunc of every row, beside the ring (ep_pool_terminated_of)
+  uint32_t term_stride;
 };
 
 __device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off) {
@@ -90,6 +92,7 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off,
 template <int S_CT>
 __global__ __launch_bounds__(kBlock) void dummy_step_server(ServerArgs a) {
   __shared__ Stage st;
+  __shared__ __align__(16) uint8_t s_term[kBlock];
   __shared__ uint32_t s_go;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int S = S_CT > 0 ? S_CT : a.pc.S;
@@ -144,6 +147,8 @@ __global__ __launch_bounds__(kBlock) void dummy_step_server(ServerArgs a) {
     char* const slot_base = a.ring.ring + (uint64_t)slot * a.ring.stride;
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)slot_base, 0, (int)(uint32_t)a.ring.stride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t term_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.term + (uint64_t)slot * a.term_stride), 0, (int)a.term_stride, 0x00020000);
     for (int j = 0; j < a.tiles_per_wg; ++j) {
       const int tile = (int)blockIdx.x + j * (int)n_wg;
       if (tile >= a.num_tiles) break;
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(kBlock) void dummy_step_server(ServerArgs a) {
       st.discount[tid] = o.done ? 0.f : 1.f;
       st.done[tid] = o.done;
       st.trunc[tid] = o.trunc;
+      s_term[tid] = (uint8_t)(o.done & (o.trunc ^ 1));
       __syncthreads();
       if (a.trace && tid == 0 && j == 0) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
       // the tile's rows: 256 consecutive rows from row tile*256, every key 16-byte aligned there.
@@ -225,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void dummy_step_server(ServerArgs a) {
         st16_sc1(out_rsrc, a.ring.off[10] + r4 + (uint32_t)lane * 16u, z);  // players.id[0] = 0
       } else {
         st16_sc1(out_rsrc, a.ring.off[4] + r4 + (uint32_t)lane * 16u, z);   // reward[0] = float(-0) = +0.0f
+        if (lane < 16) st16_sc1(term_rsrc, r1 + (uint32_t)lane * 16u, reinterpret_cast<const uint4*>(s_term)[lane]);
       }
       // obs:raw: 256 rows x S ints, row r = {state, raw1, 0, ...}; 256*S*4 bytes is a multiple of 16
       const int nvec = kBlock * S / 4;

@@ -517,6 +517,8 @@ int server_start(ep_pool* p, const void* const* arrs) {
   a.env_id = (const int32_t*)arrs[0];
   a.players_env_id = (const int32_t*)arrs[1];
   a.list_action = (const double*)arrs[2];
+  a.term = p->d_term;
+  a.term_stride = (uint32_t)p->term_stride;
   a.env = p->d_env;
   a.stats = p->stats;
   a.ring.ring = p->d_ring;
@@ -1599,8 +1601,8 @@ int ep_pool_terminated_of(ep_pool* p, const ep_batch* b, void** term) {
     return fail(EP_ERR_INVALID, "not a batch of device views of this pool");
   const size_t slot = (size_t)(first - p->d_ring) / p->slot_stride;
   if (p->slot_term_seq[slot] != b->seq + 1)
-    return fail(EP_ERR_INVALID, "no terminated array for this batch (its rows came from a rollout, the resident step kernel, "
-                                "host memory or a multi-player pool, or the slot has been handed out again): use ep_terminated_many");
+    return fail(EP_ERR_INVALID, "no terminated array for this batch (its rows came from a rollout, from host memory or a "
+                                "multi-player pool, or the slot has been handed out again): use ep_terminated_many");
   *term = p->d_term + slot * p->term_stride;
   return EP_OK;
 }
@@ -1760,7 +1762,6 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
       if (p->step_warm) { p->idle_streak = 0; p->server_fresh = false; }
       const uint64_t bi = p->step_bi;
       const int slot = (int)(bi % (uint64_t)p->Q);
-      p->slot_term_seq[slot] = 0;  // (the resident kernel does not write d_term)
       const int status = status_of_err_bits(take_err_bits(p, err_index(p, bi)), "step");
       p->alloc_count += (uint64_t)p->B;  // one whole batch allocated ...
       p->done_ptr += 1;                  // ... and received
@@ -1770,6 +1771,7 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
       out->num_rows = p->N;
       out->num_player_rows = p->N;
       out->seq = p->recv_seq++;
+      p->slot_term_seq[slot] = out->seq + 1;  // (the resident kernel writes d_term as well)
       char* base = p->d_ring + (size_t)slot * p->slot_stride;
       for (int k = 0; k < 12; ++k) {
         ep_array& a = out->arrays[k];

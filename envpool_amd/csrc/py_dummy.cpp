@@ -272,6 +272,25 @@ struct DummyPool {
     return py::make_tuple(out, b.num_rows, b.num_player_rows);
   }
 
+  // The same for a front-end that keeps its views per ring slot: (first address, rows, address of
+  // the batch's `terminated` array or 0), descriptors on request (_last_descs).
+  py::tuple step_device_slot(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims) {
+    if (ptrs.size() != 5 || dims.size() != 5) throw std::invalid_argument("need 5 pointers and 5 dims");
+    const void* p[5];
+    for (int i = 0; i < 5; ++i) p[i] = reinterpret_cast<const void*>(ptrs[i]);
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_step(pool, 5, p, dims.data(), &last_batch);
+    }
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    if (batch_with_error) throw std::runtime_error(ep_last_error());
+    void* term = nullptr;
+    if (ep_pool_terminated_of(pool, &last_batch, &term) != EP_OK) term = nullptr;
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows, reinterpret_cast<uintptr_t>(term));
+  }
+
   // ep_pool_step in two halves (ep_pool_step_begin / ep_pool_step_end): a front-end over several
   // pools rings every pool first and then waits for each.
   void step_begin(const std::vector<uintptr_t>& ptrs, const std::vector<int64_t>& dims) {
@@ -457,6 +476,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_recv_on_stream", &DummyPool::recv_on_stream, py::arg("stream") = 0)
       .def("_send_device", &DummyPool::send_device)
       .def("_step_device", &DummyPool::step_device)
+      .def("_step_device_slot", &DummyPool::step_device_slot)
       .def("_step_begin", &DummyPool::step_begin)
       .def("_step_end", &DummyPool::step_end)
       .def("_server_stats", &DummyPool::server_stats)

@@ -263,11 +263,11 @@ int ep_pool_send_on_stream(ep_pool* pool, void* stream, int32_t n_arrays, const 
 int ep_pool_set_stream(ep_pool* pool, void* stream, int32_t own);
 
 /* gymnasium's `terminated = done & ~truncated` (gymnasium_envpool.py:73-88) of a batch handed out as
- * device views, WITHOUT a launch: the one-launch-per-send step kernels write it beside the ring slot
- * (one byte per row, valid as long as the batch's views). *term = uint8[num_rows] on EP_OK;
- * EP_ERR_INVALID when this batch has none - rows written by ep_pool_rollout, by the resident kernel of
- * ep_pool_step, from host memory into a pinned block, by a multi-player pool, or a slot that has been
- * handed out again since: compute it with ep_terminated_many then. */
+ * device views, WITHOUT a launch: the one-launch-per-send step kernels and the resident kernel of
+ * ep_pool_step write it beside the ring slot (one byte per row, valid as long as the batch's views).
+ * *term = uint8[num_rows] on EP_OK; EP_ERR_INVALID when this batch has none - rows written by
+ * ep_pool_rollout, from host memory into a pinned block, by a multi-player pool, or a slot that has
+ * been handed out again since: compute it with ep_terminated_many then. */
 int ep_pool_terminated_of(ep_pool* pool, const ep_batch* batch, void** term);
 
 /* Reports (and clears) what the kernels of batches handed out in stream order have flagged SO FAR:

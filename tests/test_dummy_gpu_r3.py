@@ -322,14 +322,27 @@ def test_step_on_stream_no_host_wait_matches_oracle():
     o._send([ids, penv_all[t], np.repeat(lane_all[t][:, None], 6, axis=1), ids * 0, ids * 0])
     want = o._recv()
     assert_batches_equal([None if k == 9 else host[k][t] for k in range(12)], want, f"adopted stream, step {t}")
-  # batches written by the resident kernel of ep_pool_step or by a rollout carry no such array
+  # the resident kernel of ep_pool_step writes the array as well (several steps, so that envs finish);
+  # a rollout's batches carry none
   assert L.ep_pool_set_stream(g.handle, None, 1) == 0, L.ep_last_error()
   t_penv.copy_(t_ids); torch.cuda.synchronize()
-  assert L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b)) == 0, L.ep_last_error()
-  o._send([ids, ids, np.repeat(lane_all[59][:, None], 6, axis=1), ids * 0, ids * 0]); o._recv()
-  served = g.server_stats()[2]
-  rc = L.ep_pool_terminated_of(g.handle, C.byref(b), C.byref(term))
-  assert (rc == capi.EP_ERR_INVALID and term.value is None) if served else rc == 0
+  seen = 0
+  for t in range(40):
+    assert L.ep_pool_step(g.handle, 5, ptrs, dims, C.byref(b)) == 0, L.ep_last_error()
+    o._send([ids, ids, np.repeat(lane_all[59][:, None], 6, axis=1), ids * 0, ids * 0])
+    want = o._recv()
+    assert L.ep_pool_terminated_of(g.handle, C.byref(b), C.byref(term)) == 0, L.ep_last_error()
+    got = interop.as_torch((term.value, (n,), "|b1"), device=dev).cpu().numpy()
+    assert got.tobytes() == (want[3] & ~want[7]).tobytes(), t
+    seen += int(got.sum())
+  assert seen > 0 and g.server_stats()[2] > 0
+  strides = (C.c_int64 * 5)(0, 0, 0, 0, 0)
+  assert L.ep_pool_rollout(g.handle, 2, 5, ptrs, dims, strides) == 0, L.ep_last_error()
+  two = (capi.Batch * 2)()
+  assert L.ep_pool_recv_many(g.handle, capi.EP_MEM_DEVICE, 2, two) == 0, L.ep_last_error()
+  assert L.ep_pool_terminated_of(g.handle, C.byref(two[1]), C.byref(term)) == capi.EP_ERR_INVALID and term.value is None
+  for t in range(2):
+    o._send([ids, ids, np.repeat(lane_all[59][:, None], 6, axis=1), ids * 0, ids * 0]); o._recv()
   # back on its own stream the blocking calls are what they were
   assert L.ep_pool_set_stream(g.handle, None, 1) == 0, L.ep_last_error()
   assert L.ep_pool_stream(g.handle) != side.cuda_stream
