@@ -373,6 +373,20 @@ struct DummyPool {
     }
     epy::check(rc);
   }
+  // ep_pool_step_end for a front-end that keeps its views per ring slot (see _step_device_slot)
+  py::tuple step_end_slot() {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_step_end(pool, &last_batch);
+    }
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    if (batch_with_error) throw std::runtime_error(ep_last_error());
+    void* term = nullptr;
+    if (ep_pool_terminated_of(pool, &last_batch, &term) != EP_OK) term = nullptr;
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows, reinterpret_cast<uintptr_t>(term));
+  }
   py::tuple server_stats() {
     uint64_t a = 0, b = 0, c = 0;
     int64_t d = 0;
@@ -479,6 +493,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_step_device_slot", &DummyPool::step_device_slot)
       .def("_step_begin", &DummyPool::step_begin)
       .def("_step_end", &DummyPool::step_end)
+      .def("_step_end_slot", &DummyPool::step_end_slot)
       .def("_server_stats", &DummyPool::server_stats)
       .def("_send_on_stream", &DummyPool::send_on_stream)
       .def("_recv_slot_on_stream", &DummyPool::recv_slot_on_stream)

@@ -670,7 +670,31 @@ class ShardedTorchMixin:
         for r in range(begun):  # the steps that were rung must be ended before anything else can run
           self._shards[r]._step_end()
         raise
-      return self._result([self._shard_out(r, self._shards[r]._step_end()[0], False) for r in range(self._K)], range(self._K))
+      # the blocking form keeps its results per ring slot as well (python/streamstep.py); the kernels
+      # that served the step wrote `terminated` beside the slot, so nothing is launched here
+      from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+      if not hasattr(self, "_sh_slots"):
+        self._sh_slots = [dict() for _ in range(self._K)]
+        self._sh_adopted = [None] * self._K
+      ents, hs = [], []
+      first_error = None
+      for r in range(self._K):
+        shard = self._shards[r]
+        try:
+          key = shard._step_end_slot() if hasattr(shard, "_step_end_slot") else None
+        except Exception as e:  # (every shard that was rung must be ended: remember the first error)
+          first_error = first_error or e
+          continue
+        if key is None:
+          ents.append([self._shard_out(r, shard._step_end()[0], False), None])
+        else:
+          ent = self._sh_slots[r].get(key)
+          ents.append(ent if ent is not None else slot_entry(self, shard._last_descs()[0], self._shard_dev(r), self._sh_slots[r], key))
+        hs.append(current_stream_handle(self._shard_dev(r)))
+      if first_error is not None:
+        raise first_error
+      refresh_terminated(ents, hs)
+      return self._result([e[0] for e in ents], range(self._K))
     self.send_torch(action, env_id, owners)
     return self.recv_torch()
 
