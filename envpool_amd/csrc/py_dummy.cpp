@@ -222,6 +222,22 @@ struct DummyPool {
     return py::make_tuple(out, b.num_rows, b.num_player_rows);
   }
 
+  // Blocking recv of device views for a front-end that keeps its views per ring slot: (first
+  // address, rows, address of the batch's `terminated` array or 0); descriptors via _last_descs.
+  py::tuple recv_device_slot() {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_recv(pool, EP_MEM_DEVICE, &last_batch);
+    }
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    if (batch_with_error) throw std::runtime_error(ep_last_error());
+    void* term = nullptr;
+    if (ep_pool_terminated_of(pool, &last_batch, &term) != EP_OK) term = nullptr;
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows, reinterpret_cast<uintptr_t>(term));
+  }
+
   // Stream-ordered form (ep_pool_recv_on_stream): the same descriptors at once; `stream` (a
   // hipStream_t as an integer, 0 = the pool's own step stream, _stream()) is made to wait for
   // the kernels that write the batch instead of the host.
@@ -485,6 +501,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
       // additive (no reference counterpart)
       .def("_recv_device", &DummyPool::recv_device)
+      .def("_recv_device_slot", &DummyPool::recv_device_slot)
       .def("_try_recv", &DummyPool::try_recv)
       .def("_try_recv_device", &DummyPool::try_recv_device)
       .def("_recv_on_stream", &DummyPool::recv_on_stream, py::arg("stream") = 0)

@@ -204,6 +204,21 @@ class EnvPoolFrontEnd:
     a YGOPro pool, until `ring_depth - 1` further batches of a Dummy pool)."""
     if not hasattr(self, "_recv_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
+    if not reset and hasattr(self, "_recv_device_slot") and self._cfg["max_num_players"] == 1:
+      # the result over a ring slot's views is kept (python/streamstep.py), and the step kernels left
+      # `terminated` beside the slot: no torch launch per batch
+      import torch
+      if not hasattr(self, "_torch_dev"):
+        self._torch_dev = torch.device("cuda", self._cfg.get("device_id", 0))
+        self._torch_views = {}
+      if not hasattr(self, "_slot_results"):
+        self._slot_results = {}
+      key = self._recv_device_slot()
+      ent = self._slot_results.get(key)
+      if ent is None:
+        ent = slot_entry(self, self._last_descs()[0], self._torch_dev, self._slot_results, key)
+      refresh_terminated((ent,), (current_stream_handle(self._torch_dev),))
+      return ent[0]
     descs, _, _ = self._recv_device()
     return self._with_mask(self._torch_out(descs, reset), self._torch_view)
 

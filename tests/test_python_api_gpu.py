@@ -191,6 +191,36 @@ def test_rollout_torch_front_end(n):
   env.close()
 
 
+@pytest.mark.parametrize("kw", [dict(num_envs=512), dict(num_envs=96, batch_size=32)])
+def test_recv_torch_front_end(kw):
+  """send (host arrays) + recv_torch of a Dummy pool, sync and async: the batch as torch views of
+  the ring slot, results kept per slot, `terminated` from the step kernels' array beside the slot
+  (no torch launch); equal to the oracle batch by batch while the ring's slots come round."""
+  import torch
+  import envpool_amd
+  from oracle.dummy_oracle import DummyOracle
+  env = envpool_amd.make("Dummy-v0", "gymnasium", seed=3, **kw)
+  o = DummyOracle(seed=3, **kw)
+  n, bsz = kw["num_envs"], kw.get("batch_size", kw["num_envs"])
+  ids = np.arange(n, dtype=np.int32)
+  env.async_reset(); o._reset(ids)
+  seen_term = False
+  for it in range(60):
+    res = env.recv_torch()
+    want = o._recv()
+    obs, rew, term, trunc, info = res
+    assert obs["raw"].is_cuda and obs["raw"].cpu().numpy().tobytes() == want[8].tobytes(), it
+    assert info["env_id"].cpu().numpy().tobytes() == want[0].tobytes() and info["elapsed_step"].cpu().numpy().tobytes() == want[2].tobytes(), it
+    assert trunc.cpu().numpy().tobytes() == want[7].tobytes() and term.cpu().numpy().tobytes() == (want[3] & ~want[7]).tobytes(), it
+    seen_term = seen_term or bool((want[3] & ~want[7]).any())
+    sel = np.asarray(want[0])
+    a = dummy_action(sel)
+    env.send({"list_action": a[2], "players.action": a[3], "players.id": a[4]}, sel)
+    o._send(a)
+  assert seen_term
+  env.close()
+
+
 def test_close_releases_the_pool():
   """Additive close() (gym's convention): the device memory goes at once, later calls are refused."""
   import envpool_amd
