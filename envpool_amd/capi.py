@@ -280,6 +280,14 @@ class DummyPoolC:
         if h.nbytes:
           assert L.hipMemcpy(h.ctypes.data, a.data, h.nbytes, 2) == 0
         out.append(h)
+      # the step kernel's `terminated` array beside the slot (ep_pool_terminated_of), kept for callers that check it
+      term = C.c_void_p()
+      self.last_terminated = None
+      if L.ep_pool_terminated_of(self._h, C.byref(b), C.byref(term)) == EP_OK:
+        t = np.zeros(b.num_rows, np.uint8)
+        if t.nbytes:
+          assert L.hipMemcpy(t.ctypes.data, term, t.nbytes, 2) == 0
+        self.last_terminated = t
     finally:
       _check(L.ep_pool_sync(self._h))
       for d in dptr:

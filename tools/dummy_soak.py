@@ -88,6 +88,8 @@ def main(rounds=int(os.environ.get("SOAK_POOLS", "60"))):
         o._send(a)
         want = o._recv()
         assert_batches_equal(got, want, f"pool {kw} it {it} stream-ordered mode {mode}")
+        assert g.last_terminated is not None and g.last_terminated.tobytes() == (np.asarray(want[3]) & ~np.asarray(want[7])).astype(np.uint8).tobytes(), \
+            f"pool {kw} it {it}: terminated beside the slot"
         last_ids = np.asarray(want[0])
         steps_total += len(sel)
         continue
