@@ -8,7 +8,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from .spec import check_unique
-from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+from .streamstep import current_stream_handle, fresh, refresh_terminated, slot_entry
 from .tree import Layout
 
 try:  # dm_env is optional; the local TimeStep has the same fields and helpers
@@ -218,7 +218,7 @@ class EnvPoolFrontEnd:
       if ent is None:
         ent = slot_entry(self, self._last_descs()[0], self._torch_dev, self._slot_results, key)
       refresh_terminated((ent,), (current_stream_handle(self._torch_dev),))
-      return ent[0]
+      return fresh(ent[0])
     descs, _, _ = self._recv_device()
     return self._with_mask(self._torch_out(descs, reset), self._torch_view)
 
@@ -240,12 +240,12 @@ class EnvPoolFrontEnd:
     A sync single-player pool stepped as a whole is stepped IN STREAM ORDER by default
     (stream_ordered=None or True): the step is enqueued on torch's current stream, which the pool
     adopts as its step stream (ep_pool_set_stream + ep_pool_step_on_stream), and the call returns at
-    once - one kernel launch, no host wait (6 us per call at 65 536 envs). The result is valid for
+    once - one kernel launch, no host wait (7 us per call at 65 536 envs). The result is valid for
     work queued on that stream afterwards, like the output of any torch op (reading it on the host
     synchronises the stream), and a step's error (the list_action self-check) surfaces at a later
     step or at `_sync()` rather than at the step itself, as CUDA errors do in torch.
 
-    stream_ordered=False is the BLOCKING form (ep_pool_step, 9 us): the rows are complete and
+    stream_ordered=False is the BLOCKING form (ep_pool_step, 10 us): the rows are complete and
     errors are raised when the call returns. It takes no kernel launch (the pool's resident kernel
     answers a doorbell) as long as the action tensors keep their addresses: pass contiguous int32 /
     float64 tensors and reuse them (a tensor that needs a dtype or layout conversion is copied into
@@ -337,7 +337,7 @@ class EnvPoolFrontEnd:
     # the result over this ring slot's views is kept (python/streamstep.py); `terminated` is its one
     # computed element: refreshed by one small launch on torch's stream, like `done > trunc` would be
     refresh_terminated((ent,), (h,))
-    return ent[0]
+    return fresh(ent[0])
 
   def rollout_torch(self, action, T: Optional[int] = None):
     """T lockstep steps of every env in ONE kernel launch (ep_pool_rollout), for action sequences
@@ -396,7 +396,7 @@ class EnvPoolFrontEnd:
       ent = self._slot_results.get(key)
       ents.append(ent if ent is not None else slot_entry(self, self._descs_of(i)[0], dev, self._slot_results, key))
     refresh_terminated(ents, [h] * T)
-    return [e[0] for e in ents]
+    return [fresh(e[0]) for e in ents]
 
   def __repr__(self) -> str:
     cfg = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())

@@ -526,7 +526,7 @@ class ShardedTorchMixin:
     of all parts is refreshed by one more launch; the host waits for nothing. Results are kept per
     ring slot (python/streamstep.py)."""
     import torch
-    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    from .streamstep import current_stream_handle, fresh, refresh_terminated, slot_entry
     if not hasattr(self, "_sh_slots"):
       self._sh_slots = [dict() for _ in range(self._K)]
       self._sh_adopted = [None] * self._K
@@ -554,7 +554,7 @@ class ShardedTorchMixin:
       ent = self._sh_slots[r].get(key)
       ents.append(ent if ent is not None else slot_entry(self, shard._last_descs()[0], self._shard_dev(r), self._sh_slots[r], key))
     refresh_terminated(ents, hs)  # one launch per device on torch's stream
-    return self._result([e[0] for e in ents], range(self._K))
+    return self._result([fresh(e[0]) for e in ents], range(self._K))
 
   def rollout_torch(self, action, T=None):
     """T lockstep steps of every env, ONE launch per shard (ep_pool_rollout), for action sequences
@@ -566,7 +566,7 @@ class ShardedTorchMixin:
     `ring_depth >= T`."""
     import torch
     from .pool import _flatten_action
-    from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+    from .streamstep import current_stream_handle, fresh, refresh_terminated, slot_entry
     self._need_device_path()
     if not (self._sync and not self._pending and all(hasattr(s, "_recv_slots_on_stream") for s in self._shards)):
       raise RuntimeError(f"{type(self).__name__}: rollout_torch needs a sync pool of Dummy shards with nothing outstanding")
@@ -625,7 +625,7 @@ class ShardedTorchMixin:
         ent = self._sh_slots[r].get(key)
         if ent is None:
           ent = slot_entry(self, shard._descs_of(t)[0], dev, self._sh_slots[r], key)
-        steps[t].append(ent[0])
+        steps[t].append(fresh(ent[0]))
         ents_all.append(ent)
         hs_all.append(hs[r])
     refresh_terminated(ents_all, hs_all)
@@ -672,7 +672,7 @@ class ShardedTorchMixin:
         raise
       # the blocking form keeps its results per ring slot as well (python/streamstep.py); the kernels
       # that served the step wrote `terminated` beside the slot, so nothing is launched here
-      from .streamstep import current_stream_handle, refresh_terminated, slot_entry
+      from .streamstep import current_stream_handle, fresh, refresh_terminated, slot_entry
       if not hasattr(self, "_sh_slots"):
         self._sh_slots = [dict() for _ in range(self._K)]
         self._sh_adopted = [None] * self._K
@@ -694,7 +694,7 @@ class ShardedTorchMixin:
       if first_error is not None:
         raise first_error
       refresh_terminated(ents, hs)
-      return self._result([e[0] for e in ents], range(self._K))
+      return self._result([fresh(e[0]) for e in ents], range(self._K))
     self.send_torch(action, env_id, owners)
     return self.recv_torch()
 

@@ -70,6 +70,19 @@ def refresh_terminated(ents, handles):
     plan.launch(h)
 
 
+def _copy_dict(d):
+  return {k: (_copy_dict(v) if type(v) is dict else v) for k, v in d.items()}
+
+
+def fresh(res):
+  """A kept result as it is handed out: the tensors are the slot's views, the dicts around them are
+  new ones every time, as in the reference (a caller that adds a key to `info` must not find it
+  again when the slot comes round)."""
+  if type(res) is tuple:
+    return tuple(_copy_dict(x) if type(x) is dict else x for x in res)
+  return res
+
+
 def current_stream_handle(dev):
   """The raw hipStream_t of torch's current stream on `dev` as an integer. (torch.cuda.current_stream
   builds a Stream object, 4 us; the raw getter the compilers in torch use costs a tenth of that.)"""

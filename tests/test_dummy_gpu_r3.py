@@ -395,6 +395,8 @@ def test_step_torch_stream_ordered_front_end():
     seen_term = seen_term or bool((want[3] & ~want[7]).any())
   for t in range(300):
     res = env.step_torch(act, stream_ordered=True)
+    assert "mine" not in res[-1] and "mine" not in res[0]  # (the dicts around the kept views are new ones every time)
+    res[-1]["mine"] = res[0]["mine"] = t
     one._send(dummy_action(ids, players_env_id=pe))
     want = one._recv()
     seen_term = seen_term or bool((want[3] & ~want[7]).any())
