@@ -417,3 +417,44 @@ def test_step_torch_stream_ordered_front_end():
   env._send(a); one._send(a)
   assert_batches_equal(env._recv(), one._recv(), "numpy step afterwards")
   env.close()
+
+
+def test_terminated_many_odd_shapes():
+  """ep_terminated_many through the C ABI: 20 arrays in one call (two launches of 16 and 4), lengths
+  from 0 to 70 001 bytes, pointers 16-byte aligned and not (the bytewise path and the tails), against
+  numpy; bytes past each array's end stay untouched; bad arguments are refused."""
+  import torch
+
+  from envpool_amd import capi
+  L = capi.lib()
+  dev = torch.device("cuda", 0)
+  rng = np.random.default_rng(12)
+  lens = [0, 1, 15, 16, 17, 255, 256, 4095, 4096, 4097, 65536, 70001, 33, 64, 1000, 31, 48, 7, 12345, 2]
+  offs = [0, 0, 0, 0, 0, 3, 0, 1, 0, 16, 0, 5, 8, 0, 2, 0, 0, 9, 0, 1]
+  k = len(lens)
+  pad = 64
+  bufs, want, outs = [], [], []
+  dptr, tptr, optr = (C.c_void_p * k)(), (C.c_void_p * k)(), (C.c_void_p * k)()
+  n = (C.c_int64 * k)(*lens)
+  for i, (ln, off) in enumerate(zip(lens, offs)):
+    d = rng.integers(0, 2, ln, dtype=np.uint8)
+    t = (rng.integers(0, 2, ln, dtype=np.uint8) & d) if i % 3 else rng.integers(0, 2, ln, dtype=np.uint8)  # trunc without done too
+    td = torch.zeros(ln + off + pad, dtype=torch.uint8, device=dev); td[off:off + ln] = torch.from_numpy(d).to(dev)
+    tt = torch.zeros(ln + off + pad, dtype=torch.uint8, device=dev); tt[off:off + ln] = torch.from_numpy(t).to(dev)
+    to = torch.full((ln + off + pad,), 0x5A, dtype=torch.uint8, device=dev)
+    bufs.append((td, tt))
+    outs.append(to)
+    want.append(d & ~t & 1)
+    dptr[i], tptr[i], optr[i] = td.data_ptr() + off, tt.data_ptr() + off, to.data_ptr() + off
+  torch.cuda.synchronize()
+  stream = torch.cuda.current_stream(dev).cuda_stream
+  assert L.ep_terminated_many(k, dptr, tptr, optr, n, 0, C.c_void_p(stream)) == 0, L.ep_last_error()
+  torch.cuda.synchronize()
+  for i, (ln, off) in enumerate(zip(lens, offs)):
+    got = outs[i].cpu().numpy()
+    assert got[off:off + ln].tobytes() == want[i].astype(np.uint8).tobytes(), i
+    assert (got[:off] == 0x5A).all() and (got[off + ln:] == 0x5A).all(), i
+  assert L.ep_terminated_many(0, None, None, None, None, -1, None) == 0
+  assert L.ep_terminated_many(-1, dptr, tptr, optr, n, -1, None) == capi.EP_ERR_INVALID
+  bad = (C.c_int64 * k)(*([-1] + lens[1:]))
+  assert L.ep_terminated_many(k, dptr, tptr, optr, bad, -1, None) == capi.EP_ERR_INVALID
