@@ -182,6 +182,24 @@ struct YgoPool {
   py::object recv_device() { return recv_device_impl(false); }
   py::object try_recv_device() { return recv_device_impl(true); }
 
+  // Blocking recv of device views for a front-end that keeps its views per output slot of the
+  // encoder (python/streamstep.py): (first address, rows); descriptors on request (_last_descs_all).
+  py::tuple recv_device_slot() {
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_ygo_pool_recv(pool, EP_MEM_DEVICE, &last_batch);
+    }
+    if (rc != EP_OK && rc != EP_ERR_ACTION_CHECK) epy::check(rc);
+    return py::make_tuple(reinterpret_cast<uintptr_t>(last_batch.arrays[0].data), last_batch.num_rows);
+  }
+  py::tuple last_descs_all() {
+    py::list out;
+    for (int k = 0; k < last_batch.num_keys; ++k) out.append(desc_any(last_batch.arrays[k]));
+    return py::make_tuple(out, last_batch.num_rows, last_batch.num_rows);
+  }
+  ep_batch last_batch{};
+
   // info:env_id of the batch received last, from host memory (a copy: the library's array only lives
   // until the next recv)
   py::array_t<int32_t> last_env_ids() {
@@ -243,6 +261,8 @@ PYBIND11_MODULE(ygopro_envpool, m) {
       .def("_recv_device_all", &YgoPool::recv_device)
       .def("_try_recv_all", &YgoPool::try_recv_all)
       .def("_try_recv_device_all", &YgoPool::try_recv_device)
+      .def("_recv_device_slot", &YgoPool::recv_device_slot)
+      .def("_last_descs_all", &YgoPool::last_descs_all)
       .def("_last_env_ids", &YgoPool::last_env_ids)
       .def("_set_recv_timeout", &YgoPool::set_recv_timeout)
       .def("_num_threads", &YgoPool::num_threads)

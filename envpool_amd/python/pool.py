@@ -204,9 +204,10 @@ class EnvPoolFrontEnd:
     a YGOPro pool, until `ring_depth - 1` further batches of a Dummy pool)."""
     if not hasattr(self, "_recv_device"):
       raise RuntimeError(f"{type(self).__name__} has no device-resident path")
-    if not reset and hasattr(self, "_recv_device_slot") and self._cfg["max_num_players"] == 1:
-      # the result over a ring slot's views is kept (python/streamstep.py), and the step kernels left
-      # `terminated` beside the slot: no torch launch per batch
+    if not reset and hasattr(self, "_recv_device_slot") and (getattr(self, "_fixed_rows", False) or self._cfg["max_num_players"] == 1):
+      # the result over a slot's views is kept (python/streamstep.py: a Dummy pool's ring slots and a
+      # YGOPro encoder's output slots come round again); `terminated` comes from the step kernels'
+      # array beside the slot where there is one, else from one small launch
       import torch
       if not hasattr(self, "_torch_dev"):
         self._torch_dev = torch.device("cuda", self._cfg.get("device_id", 0))
@@ -217,6 +218,14 @@ class EnvPoolFrontEnd:
       ent = self._slot_results.get(key)
       if ent is None:
         ent = slot_entry(self, self._last_descs()[0], self._torch_dev, self._slot_results, key)
+        mask = getattr(self, "last_action_mask", None)  # (YGOPro: descriptors of the two additive keys of THIS slot)
+        if mask is not None:
+          ent.append(None)  # (the place of the terminated plan, streamstep.refresh_terminated)
+          ent.append((self.last_h_card_ids, mask))
+          if isinstance(ent[0], tuple) and isinstance(ent[0][-1], dict):
+            ent[0][-1]["action_mask"] = self._torch_view(mask)
+      elif len(ent) > 3:
+        self.last_h_card_ids, self.last_action_mask = ent[3]
       refresh_terminated((ent,), (current_stream_handle(self._torch_dev),))
       return fresh(ent[0])
     descs, _, _ = self._recv_device()

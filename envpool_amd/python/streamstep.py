@@ -50,9 +50,11 @@ def refresh_terminated(ents, handles):
     e = ents[0]
     if e[1] is not None:
       if len(e) < 3:
+        e.append(None)
+      if e[2] is None:
         from ..dummy.dummy_envpool import TermPlan
         p = e[1]
-        e.append(TermPlan([p[0]], [p[1]], [p[2]], [p[3]], p[4]))
+        e[2] = TermPlan([p[0]], [p[1]], [p[2]], [p[3]], p[4])
       e[2].launch(handles[0])
     return
   by_dev = {}

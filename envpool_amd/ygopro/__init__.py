@@ -198,6 +198,15 @@ class _YGOProEnvPool(_YGOProNativePool):
     self.last_h_card_ids, self.last_action_mask = descs[16], descs[17]
     return descs[:16], rows, prows
 
+  _fixed_rows = True  # (player rows == rows: a slot's views have the same shapes whenever it comes round)
+
+  def _last_descs(self):
+    """Descriptors of the batch `_recv_device_slot` handed out last (the 16 `_state_keys`); the two
+    additive keys are noted for `last_h_card_ids` / `last_action_mask` as `_recv_device` does."""
+    descs, rows, prows = self._last_descs_all()
+    self.last_h_card_ids, self.last_action_mask = descs[16], descs[17]
+    return descs[:16], rows, prows
+
   @property
   def last_env_ids(self) -> np.ndarray:
     """Additive: `info:env_id` of the batch received last as a host array, from host memory (the
