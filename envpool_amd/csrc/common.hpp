@@ -33,6 +33,28 @@ inline int fail(int code, const char* fmt, ...) {
                          __LINE__);                                                                \
   } while (0)
 
+// Every entry point works on ITS object's device and leaves the calling thread's current device as
+// it found it: a process that drives several GPUs (python/sharded.py over K devices, or a caller with
+// torch beside it, whose notion of "the current device" is HIP's) must not find it changed by a pool
+// or encoder call.
+struct DeviceScope {
+  int prev = -1;
+  bool changed = false;
+  hipError_t enter(int dev) {
+    if (changed) return hipSuccess;
+    if (hipGetDevice(&prev) == hipSuccess && prev == dev) return hipSuccess;
+    const hipError_t e = hipSetDevice(dev);
+    changed = e == hipSuccess && prev >= 0;
+    return e;
+  }
+  ~DeviceScope() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+#define EP_ENTER_DEVICE(dev)       \
+  ::epc::DeviceScope _dev_scope;   \
+  HIP_TRY(_dev_scope.enter(dev))
+
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 

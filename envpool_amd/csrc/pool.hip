@@ -201,11 +201,6 @@ const int kSlotDtype[11] = {EP_I32, EP_I32, EP_I32, EP_BOOL, EP_F32, EP_F32,
                             EP_I32, EP_BOOL, EP_I32, EP_BOOL, EP_I32};
 const int kSlotElem[11] = {4, 4, 4, 1, 4, 4, 4, 1, 4, 1, 4};
 
-int set_device(ep_pool* p) {
-  HIP_TRY(hipSetDevice(p->device));
-  return EP_OK;
-}
-
 epk::SlotPtrs slot_ptrs_at(ep_pool* p, char* b) {  // the key arrays of one batch laid out at `b`
   epk::SlotPtrs s;
   s.env_id = (int32_t*)(b + p->key_off[0]);
@@ -821,7 +816,8 @@ __global__ void terminated_many_kernel(TermArgs a) {
 
 int ep_terminated_many(int32_t k, const void* const* done, const void* const* trunc, void* const* out, const int64_t* n,
                        int32_t device, void* stream) {
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  ::epc::DeviceScope _dev_scope;
+  if (device >= 0) HIP_TRY(_dev_scope.enter(device));
   if (k < 0 || (k > 0 && (!done || !trunc || !out || !n))) return fail(EP_ERR_INVALID, "bad argument");
   for (int i0 = 0; i0 < k; i0 += kTermParts) {
     TermArgs a{};
@@ -845,7 +841,8 @@ int ep_terminated_many(int32_t k, const void* const* done, const void* const* tr
 }
 
 int ep_stream_synchronize(int32_t device, void* stream) {
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  ::epc::DeviceScope _dev_scope;
+  if (device >= 0) HIP_TRY(_dev_scope.enter(device));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return EP_OK;
 }
@@ -894,7 +891,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
-  HIP_TRY(hipSetDevice(p->device));
+  EP_ENTER_DEVICE(p->device);
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   p->own_stream = p->stream;
   HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -1059,7 +1056,8 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
 
 int ep_pool_destroy(ep_pool* p) {
   if (!p) return EP_OK;
-  (void)hipSetDevice(p->device);
+  ::epc::DeviceScope _dev_scope;
+  (void)_dev_scope.enter(p->device);
   if (p->wd_started) {
     { std::lock_guard<std::mutex> lk(p->mu); p->wd_quit = true; }
     p->wd_cv.notify_all();
@@ -1114,8 +1112,8 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   if (!p || (!env_ids && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad reset arguments");
   if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   if (n == 0) return EP_OK;
   if (n > p->N) return fail(EP_ERR_INVALID, "reset of %d envs on a pool of %d", n, p->N);
@@ -1154,8 +1152,8 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
   if (np_rows > (int64_t)p->N * p->P)
     return fail(EP_ERR_INVALID, "players.env_id has %lld rows, more than num_envs*max_num_players", (long long)np_rows);
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   if (n == 0) return EP_OK;
   if (!arrays[0] || !arrays[1] || !arrays[2])
@@ -1246,8 +1244,8 @@ int ep_pool_rollout(ep_pool* p, int32_t T, int32_t n_arrays, const void* const* 
   if (!p || !arrays || !leading_dims || !step_stride_rows) return fail(EP_ERR_INVALID, "null argument");
   if (n_arrays != 5) return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays, got %d", n_arrays);
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   if (!p->is_sync)
     return fail(EP_ERR_INVALID, "rollout needs sync mode (batch_size == num_envs, max_num_players == 1)");
@@ -1374,7 +1372,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     if (p->recv_timeout_ms < 0) p->cv.wait(lk, pred);
     else if (!p->cv.wait_for(lk, std::chrono::milliseconds(p->recv_timeout_ms), pred)) return would_block();
     if (!head_ready(p, &additional)) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
-    if ((rc = set_device(p))) return rc;
+    EP_ENTER_DEVICE(p->device);
   }
   const uint64_t bi = p->done_ptr;
   const int slot = (int)(bi % (uint64_t)p->Q);
@@ -1518,16 +1516,16 @@ int ep_pool_recv(ep_pool* p, int32_t mem, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
   if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   return recv_locked(p, mem, out, lk);
 }
 
 int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : p->stream;
   return recv_locked(p, EP_MEM_DEVICE, out, lk, &cs);
 }
@@ -1535,8 +1533,8 @@ int ep_pool_recv_on_stream(ep_pool* p, void* consumer_stream, ep_batch* out) {
 int ep_pool_recv_many_on_stream(ep_pool* p, void* consumer_stream, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   hipStream_t cs = consumer_stream ? (hipStream_t)consumer_stream : p->stream;
   for (int i = 0; i < n; ++i)
     if ((rc = recv_locked(p, EP_MEM_DEVICE, out + i, lk, &cs))) return rc;
@@ -1546,8 +1544,8 @@ int ep_pool_recv_many_on_stream(ep_pool* p, void* consumer_stream, int32_t n, ep
 int ep_pool_set_stream(ep_pool* p, void* stream, int32_t own) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if (p->step_mode != 0) return fail(EP_ERR_INVALID, "ep_pool_set_stream between ep_pool_step_begin and ep_pool_step_end");
   hipStream_t next = own ? p->own_stream : (hipStream_t)stream;
   if (next == p->stream) return EP_OK;
@@ -1570,8 +1568,8 @@ int ep_pool_send_on_stream(ep_pool* p, void* stream, int32_t n_arrays, const voi
   if (!p) return fail(EP_ERR_INVALID, "null argument");
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    int rc = set_device(p);
-    if (rc) return rc;
+    EP_ENTER_DEVICE(p->device);
+    [[maybe_unused]] int rc = EP_OK;
     hipStream_t cs = stream ? (hipStream_t)stream : p->stream;  // (NULL: the pool's step stream, as for ep_pool_recv_on_stream)
     if (cs != p->stream) {
       // the actions (and the consumer's reads of the slot this step will refill) come first
@@ -1629,8 +1627,8 @@ int ep_pool_recv_many(ep_pool* p, int32_t mem, int32_t n, ep_batch* out) {
   if (!p || !out || n < 0) return fail(EP_ERR_INVALID, "bad argument");
   if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   int status = EP_OK;
   std::string first_msg;
   for (int i = 0; i < n; ++i) {
@@ -1650,8 +1648,8 @@ int ep_pool_step_begin(ep_pool* p, int32_t n_arrays, const void* const* arrays, 
   if (n_arrays != 5) return fail(EP_ERR_INVALID, "Dummy expects 5 action arrays in _action_keys order, got %d", n_arrays);
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    int rc = set_device(p);
-    if (rc) return rc;
+    EP_ENTER_DEVICE(p->device);
+    [[maybe_unused]] int rc = EP_OK;
     if (p->step_mode != 0) return fail(EP_ERR_INVALID, "the previous ep_pool_step_begin has not been ended");
     const bool whole = leading_dims[0] == p->N && leading_dims[1] == p->N && leading_dims[2] == p->N;
     const bool aligned = arrays[0] && arrays[1] && arrays[2] && !((uintptr_t)arrays[0] & 3) && !((uintptr_t)arrays[1] & 3) &&
@@ -1713,8 +1711,8 @@ int ep_pool_step_end(ep_pool* p, ep_batch* out) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    int rc = set_device(p);
-    if (rc) return rc;
+    EP_ENTER_DEVICE(p->device);
+    [[maybe_unused]] int rc = EP_OK;
     if (p->step_mode == 0) return fail(EP_ERR_INVALID, "ep_pool_step_end without ep_pool_step_begin");
     if (p->step_mode == 1) {
       const uint32_t seq = p->server_seq;
@@ -1800,8 +1798,8 @@ int ep_pool_step(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
 int ep_pool_server_trace(ep_pool* p, uint64_t* out, int32_t max_workgroups) {
   if (!p || !out) return fail(EP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if (!p->d_server_trace) return fail(EP_ERR_INVALID, "no trace: create the pool with EP_SERVER_TRACE=1 in the environment");
   if ((rc = server_stop(p))) return rc;
   const int n = std::min(std::min(max_workgroups, p->server_wgs), 1024);
@@ -1830,8 +1828,8 @@ int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_leng
                                 void* consumer_stream) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   hipStream_t cs = (hipStream_t)consumer_stream;
   // destination buffers may still be read by the consumer's previous work (e.g. an all-gather)
@@ -1862,8 +1860,8 @@ int ep_batch_release(ep_batch* b) {
 int ep_pool_sync(ep_pool* p) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::unique_lock<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   if (p->copy_dirty) {
     p->copy_dirty = false;
@@ -1888,8 +1886,8 @@ int ep_pool_episode_stats(ep_pool* p, float* fin_return, int32_t* fin_length, in
   if (epc::bad_mem(mem)) return fail(EP_ERR_INVALID, "mem = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem);
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   hipMemcpyKind kind = mem == EP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   size_t bytes = 4 * (size_t)p->N;
@@ -1908,8 +1906,8 @@ int64_t ep_pool_checkpoint_bytes(ep_pool* p) {
 int ep_pool_checkpoint_save(ep_pool* p, void* buf) {
   if (!p || !buf) return fail(EP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   char* o = (char*)buf;
   size_t n = (size_t)p->N;
@@ -1925,8 +1923,8 @@ int ep_pool_checkpoint_save(ep_pool* p, void* buf) {
 int ep_pool_checkpoint_restore(ep_pool* p, const void* buf) {
   if (!p || !buf) return fail(EP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = server_stop(p))) return rc;
   const char* o = (const char*)buf;
   size_t n = (size_t)p->N;
@@ -2005,7 +2003,7 @@ int ep_dummy_send_noalloc(const ep_dummy_config* cfg, void* env_state, int32_t n
                                           : "output array %d must be one-dimensional", k, S);
   }
   if (cfg->device_id < 0 || cfg->device_id >= kNoallocMaxDevices) return fail(EP_ERR_INVALID, "device_id %d out of range", cfg->device_id);
-  HIP_TRY(hipSetDevice(cfg->device_id));
+  EP_ENTER_DEVICE(cfg->device_id);
   unsigned char* sc = nullptr;
   int cus = 0;
   {
@@ -2103,8 +2101,8 @@ int ep_pool_set_timing(ep_pool* p, int32_t enabled) {
 int ep_pool_kernel_time_us(ep_pool* p, double* total_us, int64_t* launches, int32_t reset) {
   if (!p) return fail(EP_ERR_INVALID, "null pool");
   std::lock_guard<std::mutex> lk(p->mu);
-  int rc = set_device(p);
-  if (rc) return rc;
+  EP_ENTER_DEVICE(p->device);
+  [[maybe_unused]] int rc = EP_OK;
   if ((rc = drain_timed(p))) return rc;
   if (total_us) *total_us = p->timed_total_us;
   if (launches) *launches = p->timed_launches;

@@ -274,7 +274,7 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
   if (e->cfg.ring_depth <= 0) e->cfg.ring_depth = 4;
   e->lay = make_layout(*cfg);
   e->device = cfg->device_id;
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   {
     // a different priority class puts the second stream on a hardware queue of its own: the two
@@ -335,7 +335,8 @@ int ep_ygo_encoder_create(const ep_ygo_config* cfg, ep_ygo_encoder** out) {
 
 int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
   if (!e) return EP_OK;
-  (void)hipSetDevice(e->device);
+  ::epc::DeviceScope _dev_scope;
+  (void)_dev_scope.enter(e->device);
   (void)hipStreamSynchronize(e->copy_stream);
   (void)hipStreamSynchronize(e->stream);
 #ifdef YGO_STAMPS
@@ -372,7 +373,7 @@ int ep_ygo_encoder_destroy(ep_ygo_encoder* e) {
 int ep_ygo_set_card_table(ep_ygo_encoder* e, const ygo_card_data* cards, int32_t n) {
   if (!e || (!cards && n > 0) || n < 0) return fail(EP_ERR_INVALID, "bad card table");
   std::lock_guard<std::mutex> lk(e->mu);
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   // entries first (a repeated code keeps the last one, like map[code] = ...)
   std::vector<ygk::HashEntry> ent;
   std::vector<ygk::HashAux> ent_aux;
@@ -485,7 +486,7 @@ static int commit_slot_impl(ep_ygo_encoder* e, int32_t n, const uint32_t* offset
   if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
   if (e->submit_idx - e->collect_idx >= e->slots.size())
     return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   const int si = (int)(e->submit_idx % e->slots.size());
   Slot& s = e->slots[si];
   if (s.rows_launched != 0)
@@ -553,7 +554,7 @@ int ep_ygo_commit_slot_rows(ep_ygo_encoder* e, int32_t row0, int32_t n_rows, int
   if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
   if (e->submit_idx - e->collect_idx >= e->slots.size())
     return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   const int si = (int)(e->submit_idx % e->slots.size());
   Slot& s = e->slots[si];
   if (s.rows_launched + n_rows > n_total)
@@ -593,7 +594,7 @@ int ep_ygo_abort_slot(ep_ygo_encoder* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   Slot& s = e->slots[(size_t)(e->submit_idx % e->slots.size())];
   if (s.rows_launched == 0) return EP_OK;
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipStreamSynchronize(e->copy_stream));
   s.rows_launched = 0;
@@ -647,7 +648,7 @@ int ep_ygo_collect(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
   if (epc::bad_mem(mem_out)) return fail(EP_ERR_INVALID, "mem_out = %d is neither EP_MEM_HOST nor EP_MEM_DEVICE", mem_out);
   std::lock_guard<std::mutex> lk(e->mu);
   if (e->collect_idx == e->submit_idx) return fail(EP_ERR_WOULD_BLOCK, "nothing submitted");
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   const int si = (int)(e->collect_idx % e->slots.size());
   Slot& s = e->slots[si];
   HIP_TRY(hipEventSynchronize(s.done));
@@ -700,7 +701,7 @@ int ep_ygo_submit_device(ep_ygo_encoder* e, const void* device_records, int32_t 
   if (!e->d_table) return fail(EP_ERR_INVALID, "no card table: call ep_ygo_set_card_table first");
   if (e->submit_idx - e->collect_idx >= e->slots.size())
     return fail(EP_ERR_RING_FULL, "%zu batches in flight: collect one first", e->slots.size());
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   const int si = (int)(e->submit_idx % e->slots.size());
   Slot& s = e->slots[si];
   s.n = n;
@@ -801,7 +802,7 @@ int ep_ygo_record_done(ep_ygo_encoder* e, uint64_t ticket) {
   if (e->a_done[si].fetch_add(1, std::memory_order_acq_rel) + 1 != B) return EP_OK;
   e->a_done[si].store(0, std::memory_order_relaxed);
   std::lock_guard<std::mutex> lk(e->mu);
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   Slot& s = e->slots[si];
   s.n = B;
   hipStream_t st = (bi & 1) ? e->copy_stream : e->stream;
@@ -867,7 +868,7 @@ int ep_ygo_recv(ep_ygo_encoder* e, int32_t mem_out, ep_batch* out) {
     if (e->a_committed[si] != bi + 1) return fail(EP_ERR_WOULD_BLOCK, "the arrival-ordered ring was closed");
   }
   lk.unlock();
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   HIP_TRY(hipEventSynchronize(e->slots[si].done));
   lk.lock();
   e->collect_idx = bi;  // (describe() numbers the batch with it)
@@ -975,7 +976,7 @@ int ep_ygo_set_recv_timeout(ep_ygo_encoder* e, int64_t milliseconds) {
 
 int ep_ygo_sync(ep_ygo_encoder* e) {
   if (!e) return fail(EP_ERR_INVALID, "null encoder");
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   HIP_TRY(hipStreamSynchronize(e->copy_stream));
   HIP_TRY(hipStreamSynchronize(e->copy_stream2));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1001,7 +1002,7 @@ int ep_ygo_set_timing(ep_ygo_encoder* e, int32_t enabled) {
 int ep_ygo_kernel_time_us(ep_ygo_encoder* e, double* total_us, int64_t* launches, int32_t reset) {
   if (!e) return fail(EP_ERR_INVALID, "null encoder");
   std::lock_guard<std::mutex> lk(e->mu);
-  HIP_TRY(hipSetDevice(e->device));
+  EP_ENTER_DEVICE(e->device);
   for (auto& ab : e->timed) {
     HIP_TRY(hipEventSynchronize(ab.second));
     float ms = 0.f;

@@ -458,3 +458,26 @@ def test_terminated_many_odd_shapes():
   assert L.ep_terminated_many(-1, dptr, tptr, optr, n, -1, None) == capi.EP_ERR_INVALID
   bad = (C.c_int64 * k)(*([-1] + lens[1:]))
   assert L.ep_terminated_many(k, dptr, tptr, optr, bad, -1, None) == capi.EP_ERR_INVALID
+
+
+def test_entry_points_leave_the_current_device_alone():
+  """A pool or encoder call runs on ITS device and leaves the calling thread's current HIP device
+  as it found it (torch's notion of the current device is HIP's). One GPU here: the calls are made
+  with the device set to 0 and with whatever the library would have to switch from; what can be
+  checked on one device is that nothing raises and the current device reads back unchanged."""
+  import torch
+
+  from envpool_amd import capi
+  L = capi.lib()
+  L.hipGetDevice.argtypes = [C.POINTER(C.c_int)]
+  cur = C.c_int(-1)
+  assert L.hipGetDevice(C.byref(cur)) == 0
+  before = cur.value
+  g, o = _pair(num_envs=256, seed=2)
+  ids = np.arange(256, dtype=np.int32)
+  g._reset(ids); g._recv()
+  g._send(dummy_action(ids)); g._recv()
+  assert L.ep_stream_synchronize(0, None) == 0 and L.ep_pool_poll_errors(g.handle) == 0
+  g.close()
+  assert L.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
+  assert torch.cuda.current_device() == before
