@@ -471,3 +471,19 @@ def test_headers_are_plain_c_and_cxx(tmp_path):
     r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include")] + extra +
                        ["-c", str(src), "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_kept_results_are_handed_out_with_new_dicts():
+  """python/streamstep.py:fresh - a step result kept per ring slot is handed out with new `obs` /
+  `info` dicts (nested ones too) around the SAME leaf objects, as the reference builds its dicts anew
+  on every recv; non-tuple results (dm's TimeStep) pass through."""
+  from envpool_amd.python.streamstep import fresh
+  leaf_a, leaf_b, leaf_c = object(), object(), object()
+  kept = ({"raw": leaf_a}, leaf_b, leaf_c, leaf_c, {"env_id": leaf_a, "players": {"env_id": leaf_b}})
+  out = fresh(kept)
+  assert out is not kept and out[1] is leaf_b and out[0] is not kept[0] and out[4] is not kept[4]
+  assert out[4]["players"] is not kept[4]["players"] and out[4]["players"]["env_id"] is leaf_b and out[0]["raw"] is leaf_a
+  out[4]["mine"] = out[4]["players"]["mine"] = 1
+  assert "mine" not in kept[4] and "mine" not in kept[4]["players"]
+  nt = ("not", "a", "result")
+  assert fresh(list(nt)) == list(nt)
