@@ -45,6 +45,7 @@ SYMBOLS = [
   "ep_last_error", "ep_version", "ep_dummy_send_noalloc", "ep_pool_step", "ep_pool_last_rollout_kernel",
   "ep_pool_step_begin", "ep_pool_step_end", "ep_pool_server_stats", "ep_pool_server_trace", "ep_pool_recv_many_on_stream",
   "ep_pool_step_on_stream", "ep_pool_send_on_stream", "ep_pool_poll_errors", "ep_pool_set_stream", "ep_terminated_many", "ep_stream_synchronize", "ep_pool_terminated_of",
+  "ep_host_blocks_create", "ep_host_blocks_take", "ep_host_blocks_give", "ep_host_blocks_destroy", "ep_pool_host_target",
 ]
 
 _bound = None
@@ -74,6 +75,11 @@ def lib():
     L.ep_pool_terminated_of.argtypes = [vp, C.POINTER(Batch), C.POINTER(vp)]
     L.ep_terminated_many.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp]
     L.ep_pool_send_on_stream.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.ep_host_blocks_create.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.ep_host_blocks_take.argtypes = [vp, C.POINTER(vp)]
+    L.ep_host_blocks_give.argtypes = [vp, vp]
+    L.ep_host_blocks_destroy.argtypes = [vp]
+    L.ep_pool_host_target.argtypes = [vp, vp, vp, C.POINTER(C.c_size_t), i64]
     L.ep_pool_server_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.ep_pool_last_rollout_kernel.argtypes = [vp]
     L.ep_pool_last_rollout_kernel.restype = C.c_char_p

@@ -35,6 +35,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "dummy_kernels.hpp"
@@ -50,6 +51,35 @@ using epc::fail;
 using epc::HostBlockOwner;
 using epc::HostBlocks;
 
+// ep_host_blocks: pinned, portable, device-mapped blocks that a caller hands to pools as result
+// targets. Every block out of the set is reference-counted: the taker holds it once, a pool that
+// was given it as a target holds it until its batch is done with it, and it goes back to the free
+// list (or is freed, after ep_host_blocks_destroy) when the last hold is dropped - so a block is
+// never unmapped while a kernel may still write it.
+struct HostBlockSet {
+  std::mutex mu;
+  std::vector<void*> free_list;
+  std::unordered_map<void*, int> holds;
+  size_t bytes = 0;
+  bool alive = true;
+  bool held(void* blk) {
+    std::lock_guard<std::mutex> lk(mu);
+    return holds.count(blk) != 0;
+  }
+  void hold(void* blk) {
+    std::lock_guard<std::mutex> lk(mu);
+    ++holds[blk];
+  }
+  void drop(void* blk) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = holds.find(blk);
+    if (it == holds.end() || --it->second > 0) return;
+    holds.erase(it);
+    if (alive && free_list.size() < 8) free_list.push_back(blk);
+    else (void)hipHostFree(blk);
+  }
+};
+
 struct SlotHost {
   uint64_t alloc_count = 0;  // StateBuffer::alloc_count_
   uint32_t shared_off = 0;   // low half of StateBuffer::offsets_
@@ -59,9 +89,21 @@ struct SlotHost {
   int mp_word = -1;        // multi-player pools: index of the player-total word of this batch
   void* host_blk = nullptr;  // direct host mode: the kernels wrote this batch straight into a pinned block, not the ring
   bool term_ok = false;      // every row so far came from a step kernel that also wrote d_term (ep_pool_terminated_of)
+  // ep_pool_host_target: this batch is delivered into the caller's arrays (direct host mode: the
+  // kernels write them, host_blk = ext_host[0] as the "direct" mark; else recv copies into them)
+  bool ext = false;
+  int64_t ext_row0 = 0;  // row of the caller's arrays that row 0 of this batch goes to
+  char* ext_host[11]{};
+  char* ext_dev[11]{};
+  std::shared_ptr<HostBlockSet> ext_home;  // the pool's hold on the block, dropped when the batch is done with it
+  void* ext_block = nullptr;
 };
 
 }  // namespace
+
+struct ep_host_blocks {
+  std::shared_ptr<HostBlockSet> set;
+};
 
 struct ep_pool {
   ep_dummy_config cfg{};
@@ -134,6 +176,13 @@ struct ep_pool {
   std::condition_variable cv;    // signalled when a send/reset has added rows (StateBuffer::Done -> sem_.signal)
   int64_t recv_timeout_ms = -1;  // ep_pool_set_recv_timeout: < 0 wait like the reference, 0 never wait, > 0 bounded
   std::shared_ptr<HostBlocks> blocks;
+  // ep_pool_host_target: where the next batch started by a send / reset is to be delivered
+  bool target_pending = false;
+  int64_t target_row0 = 0;
+  char* target_host[11]{};
+  char* target_dev[11]{};
+  std::shared_ptr<HostBlockSet> target_home;
+  void* target_block = nullptr;
   const char* last_rollout_kernel = "";  // which rollout kernel the last ep_pool_rollout launched
   // work on `stream` that no launch id covers (memsets, copies, the stats snapshot) / anything on
   // copy_stream: ep_pool_sync only has to call hipStreamSynchronize (8-10 us even on an idle stream,
@@ -214,6 +263,21 @@ epk::SlotPtrs slot_ptrs_at(ep_pool* p, char* b) {  // the key arrays of one batc
   s.raw = (int32_t*)(b + p->key_off[8]);
   s.pdone = (uint8_t*)(b + p->key_off[9]);
   s.pid = (int32_t*)(b + p->key_off[10]);
+  return s;
+}
+epk::SlotPtrs slot_ptrs_of(char* const* k) {  // the key arrays of one batch, each where the caller put it
+  epk::SlotPtrs s;
+  s.env_id = (int32_t*)k[0];
+  s.penv = (int32_t*)k[1];
+  s.elapsed = (int32_t*)k[2];
+  s.done = (uint8_t*)k[3];
+  s.reward = (float*)k[4];
+  s.discount = (float*)k[5];
+  s.step_type = (int32_t*)k[6];
+  s.trunc = (uint8_t*)k[7];
+  s.raw = (int32_t*)k[8];
+  s.pdone = (uint8_t*)k[9];
+  s.pid = (int32_t*)k[10];
   return s;
 }
 epk::SlotPtrs host_slot_ptrs(ep_pool* p, int slot) { return slot_ptrs_at(p, p->d_ring + (size_t)slot * p->slot_stride); }
@@ -560,7 +624,8 @@ int server_start(ep_pool* p, const void* const* arrs) {
 // separate event packet behind the kernel: about 1 us less on the host and on the queue).
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
               int slot, int err_w, int row0, bool force_reset, bool check_dup, const LaunchEvents& le,
-              char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr, int la_bit0 = 0) {
+              char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr, int la_bit0 = 0,
+              char* const* ext_dev = nullptr) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
@@ -570,7 +635,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.la_bit0 = la_bit0;
   a.env = p->d_env;
   a.stats = p->stats;
-  a.slot = out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
+  a.slot = ext_dev ? slot_ptrs_of(ext_dev) : out_base ? slot_ptrs_at(p, out_base) : host_slot_ptrs(p, slot);
   a.err = p->d_err + err_w;
   a.stamp = check_dup ? p->d_stamp : nullptr;
   a.stamp_val = next_stamp(p);
@@ -578,7 +643,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.n = n;
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
-  a.term = out_base ? nullptr : p->d_term + (size_t)slot * p->term_stride;
+  a.term = (out_base || ext_dev) ? nullptr : p->d_term + (size_t)slot * p->term_stride;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
   const bool dev = !force_reset && d_la && a.stamp && !p->force_generic;  // (see dummy_step_sp)
   if (p->S == 10 && dev)
@@ -645,24 +710,38 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     // otherwise rows follow the allocation order.
     int row0 = p->is_sync ? row_base + i0 : (int)(pos % B);
     SlotHost& sh = p->slots[slot];
-    if (host_mode && !sh.host_blk && sh.alloc_count == 0 && !sh.has_work) {
+    if (p->target_pending && sh.alloc_count == 0 && !sh.has_work && !sh.host_blk) {
+      // the caller's arrays for this batch (ep_pool_host_target): the hold on the block moves to the slot
+      sh.ext = true;
+      sh.ext_row0 = p->target_row0;
+      memcpy(sh.ext_host, p->target_host, sizeof(sh.ext_host));
+      memcpy(sh.ext_dev, p->target_dev, sizeof(sh.ext_dev));
+      sh.ext_home = std::move(p->target_home);
+      sh.ext_block = p->target_block;
+      p->target_pending = false;
+      p->target_block = nullptr;
+      if (host_mode) sh.host_blk = sh.ext_host[0];  // direct: the kernels write the caller's arrays (rows from ext_row0)
+    }
+    if (host_mode && !sh.host_blk && !sh.ext && sh.alloc_count == 0 && !sh.has_work) {
       void* blk = nullptr;
       if ((rc = epc::take_block(p->blocks, &blk))) break;
       sh.host_blk = blk;
     }
     char* out_base = nullptr;
-    if (sh.host_blk) {
+    if (sh.host_blk && !sh.ext) {
       void* dv = nullptr;
       if (hipHostGetDevicePointer(&dv, sh.host_blk, 0) != hipSuccess) { rc = fail(EP_ERR_HIP, "pinned result block is not device-mappable"); break; }
       out_base = (char*)dv;
     }
     LaunchEvents le;
     if ((rc = begin_launch(p, &le, st))) break;
+    const bool ext_direct = sh.ext && sh.host_blk;
     rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
-                   d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0, force_reset,
-                   !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0);
+                   d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0 + (ext_direct ? (int)sh.ext_row0 : 0), force_reset,
+                   !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0,
+                   ext_direct ? sh.ext_dev : nullptr);
     if (rc != EP_OK) { abandon_launch(p, le); break; }
-    sh.term_ok = (sh.has_work ? sh.term_ok : true) && out_base == nullptr;
+    sh.term_ok = (sh.has_work ? sh.term_ok : true) && out_base == nullptr && !ext_direct;
     sh.alloc_count += cnt;
     sh.shared_off += cnt;
     sh.written.emplace_back(row0, row0 + cnt);
@@ -1099,8 +1178,11 @@ int ep_pool_destroy(ep_pool* p) {
   if (p->h_err) (void)hipHostFree(p->h_err);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   (void)hipFree(p->d_stage);
-  for (auto& sh : p->slots)
-    if (sh.host_blk) (void)hipHostFree(sh.host_blk);  // a direct-mode batch nobody received
+  for (auto& sh : p->slots) {
+    if (sh.host_blk && !sh.ext) (void)hipHostFree(sh.host_blk);  // a direct-mode batch nobody received
+    if (sh.ext_home) sh.ext_home->drop(sh.ext_block);            // (the stream was drained above: nothing writes it any more)
+  }
+  if (p->target_home) p->target_home->drop(p->target_block);
   epc::retire_blocks(p->blocks);
   (void)hipStreamDestroy(p->own_stream);
   (void)hipStreamDestroy(p->copy_stream);
@@ -1385,14 +1467,28 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
                                 "multi-player batch is only known on the device)");
   // host output of a single-player pool: the D2H copy below is ordered behind the kernels on the
   // step stream and one synchronisation at its end serves both (no host round trip in between)
+  auto drop_target = [&]() {  // the pool is done with the caller's arrays of this batch
+    if (sh.ext_home) sh.ext_home->drop(sh.ext_block);
+    sh.ext_home.reset();
+    sh.ext_block = nullptr;
+    sh.ext = false;
+  };
   if (sh.host_blk && (mem != EP_MEM_HOST || consumer)) {
     // the batch was written straight into a pinned block (direct host mode) but is wanted as
     // device views after all: bring it into its ring slot
-    HIP_TRY(hipMemcpyAsync(p->d_ring + (size_t)slot * p->slot_stride, sh.host_blk, p->slot_stride, hipMemcpyHostToDevice, p->stream));
+    if (sh.ext) {
+      for (int k = 0; k < 11; ++k)
+        if (nrows) HIP_TRY(hipMemcpyAsync(p->d_ring + (size_t)slot * p->slot_stride + p->key_off[k],
+                                          sh.ext_host[k] + (size_t)sh.ext_row0 * p->key_rowbytes[k],
+                                          (size_t)nrows * p->key_rowbytes[k], hipMemcpyHostToDevice, p->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(p->d_ring + (size_t)slot * p->slot_stride, sh.host_blk, p->slot_stride, hipMemcpyHostToDevice, p->stream));
+    }
     if ((rc = sync_stream_unlocked(p, &lk))) return rc;
-    epc::give_block(p->blocks, sh.host_blk);
+    if (!sh.ext) epc::give_block(p->blocks, sh.host_blk);
     sh.host_blk = nullptr;
   }
+  if (sh.ext && (mem != EP_MEM_HOST || consumer)) drop_target();  // received as device views: the target stays as it was
   const bool filled_blk = sh.host_blk != nullptr;  // (still set: wanted as host memory, by the host)
   const bool one_sync = mem == EP_MEM_HOST && p->P == 1 && !consumer && !filled_blk;
   if (sh.has_work && !consumer && !one_sync)
@@ -1407,7 +1503,9 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     auto zero_rows = [&](int64_t a, int64_t b) -> int {
       if (filled_blk) {  // the kernels of this batch are done (waited for above): plain host stores
         for (int k = 0; k < 11; ++k)
-          memset((char*)sh.host_blk + p->key_off[k] + (size_t)a * p->key_rowbytes[k], 0, (size_t)(b - a) * p->key_rowbytes[k]);
+          memset((sh.ext ? sh.ext_host[k] + (size_t)sh.ext_row0 * p->key_rowbytes[k] : (char*)sh.host_blk + p->key_off[k]) +
+                     (size_t)a * p->key_rowbytes[k],
+                 0, (size_t)(b - a) * p->key_rowbytes[k]);
         return EP_OK;
       }
       p->stream_extra = true;
@@ -1460,10 +1558,14 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
     void* blk = sh.host_blk;  // direct host mode: the kernels are writing (or wrote) it already
     sh.host_blk = nullptr;
     const bool filled = blk != nullptr;
-    if (!filled && (rc = epc::take_block(p->blocks, &blk))) return rc;
+    if (!filled && !sh.ext && (rc = epc::take_block(p->blocks, &blk))) return rc;
     char* src = p->d_ring + (size_t)slot * p->slot_stride;
     if (filled) {
       // nothing to copy, and the launches that wrote it were waited for above
+    } else if (sh.ext) {  // the caller's arrays, filled from the ring slot
+      for (int k = 0; k < 11; ++k)
+        if (nrows) HIP_TRY(hipMemcpyAsync(sh.ext_host[k] + (size_t)sh.ext_row0 * p->key_rowbytes[k], src + p->key_off[k],
+                                          (size_t)nrows * p->key_rowbytes[k], hipMemcpyDeviceToHost, p->stream));
     } else if ((size_t)nrows * 2 >= (size_t)p->B) {
       HIP_TRY(hipMemcpyAsync(blk, src, p->slot_stride, hipMemcpyDeviceToHost, p->stream));
     } else {
@@ -1472,9 +1574,9 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
         if (r) HIP_TRY(hipMemcpyAsync((char*)blk + p->key_off[k], src + p->key_off[k], r * p->key_rowbytes[k], hipMemcpyDeviceToHost, p->stream));
       }
     }
-    if (!filled && (rc = sync_stream_unlocked(p, &lk))) { epc::give_block(p->blocks, blk); return rc; }
+    if (!filled && (rc = sync_stream_unlocked(p, &lk))) { if (!sh.ext) epc::give_block(p->blocks, blk); return rc; }
     if (one_sync) status = status_of_err_bits(take_err_bits(p, ew), "recv");
-    out->owner = new HostBlockOwner{p->blocks, blk};
+    if (!sh.ext) out->owner = new HostBlockOwner{p->blocks, blk};  // (the caller's arrays: no owner, ep_batch_release has nothing to do)
     base = (char*)blk;
   } else {
     base = p->d_ring + (size_t)slot * p->slot_stride;
@@ -1489,7 +1591,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
       a.shape[0] = nplayers;
       continue;
     }
-    a.data = base + p->key_off[sk];
+    a.data = (sh.ext && mem == EP_MEM_HOST) ? sh.ext_host[sk] + (size_t)sh.ext_row0 * p->key_rowbytes[sk] : base + p->key_off[sk];
     a.dtype = kSlotDtype[sk];
     a.ndim = 1;
     a.shape[0] = p->key_is_player[sk] ? nplayers : nrows;
@@ -1503,6 +1605,7 @@ int recv_locked(ep_pool* p, int32_t mem, ep_batch* out, std::unique_lock<std::mu
   sh.written.clear();
   sh.has_work = false;
   sh.mp_word = -1;
+  if (sh.ext) drop_target();
   p->slot_term_seq[slot] = (sh.term_ok && mem == EP_MEM_DEVICE && p->P == 1) ? out->seq + 1 : 0;
   sh.term_ok = false;
   if (p->is_sync) p->stepping_env_num -= nrows;
@@ -1841,6 +1944,96 @@ int ep_pool_episode_stats_async(ep_pool* p, float* fin_return, int32_t* fin_leng
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(p->stats_ev, p->stream));
   HIP_TRY(hipStreamWaitEvent(cs, p->stats_ev, 0));
+  return EP_OK;
+}
+
+int ep_host_blocks_create(size_t bytes, ep_host_blocks** out) {
+  if (!out || bytes == 0) return fail(EP_ERR_INVALID, "ep_host_blocks_create: null result pointer or zero block size");
+  auto* hb = new ep_host_blocks;
+  hb->set = std::make_shared<HostBlockSet>();
+  hb->set->bytes = bytes;
+  *out = hb;
+  return EP_OK;
+}
+
+int ep_host_blocks_take(ep_host_blocks* hb, void** block) {
+  if (!hb || !block) return fail(EP_ERR_INVALID, "null argument");
+  void* blk = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(hb->set->mu);
+    if (!hb->set->free_list.empty()) {
+      blk = hb->set->free_list.back();
+      hb->set->free_list.pop_back();
+    }
+  }
+  // portable: every device of the process can write it, whichever was current when it was made
+  if (!blk) HIP_TRY(hipHostMalloc(&blk, hb->set->bytes, hipHostMallocMapped | hipHostMallocPortable));
+  hb->set->hold(blk);
+  *block = blk;
+  return EP_OK;
+}
+
+int ep_host_blocks_give(ep_host_blocks* hb, void* block) {
+  if (!hb || !block) return fail(EP_ERR_INVALID, "null argument");
+  if (!hb->set->held(block)) return fail(EP_ERR_INVALID, "ep_host_blocks_give: not a block that is out of this set");
+  hb->set->drop(block);
+  return EP_OK;
+}
+
+int ep_host_blocks_destroy(ep_host_blocks* hb) {
+  if (!hb) return EP_OK;
+  {
+    std::lock_guard<std::mutex> lk(hb->set->mu);
+    hb->set->alive = false;
+    for (void* b : hb->set->free_list) (void)hipHostFree(b);
+    hb->set->free_list.clear();
+  }
+  delete hb;  // (blocks still held - by the caller's arrays or by a pool - are freed when the last hold goes)
+  return EP_OK;
+}
+
+int ep_pool_host_target(ep_pool* p, ep_host_blocks* hb, void* block, const size_t* key_off, int64_t row_offset) {
+  if (!p) return fail(EP_ERR_INVALID, "null pool");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (!hb && !block) {  // cancel
+    if (p->target_home) p->target_home->drop(p->target_block);
+    p->target_home.reset();
+    p->target_block = nullptr;
+    p->target_pending = false;
+    return EP_OK;
+  }
+  if (!hb || !block || !key_off) return fail(EP_ERR_INVALID, "ep_pool_host_target: null argument");
+  if (p->P > 1)
+    return fail(EP_ERR_INVALID, "ep_pool_host_target needs max_num_players == 1 (the player rows of a multi-player batch have no "
+                                "fixed place)");
+  if (!hb->set->held(block)) return fail(EP_ERR_INVALID, "ep_pool_host_target: not a block that is out of this set");
+  if (row_offset < 0 || row_offset > (int64_t)1 << 30) return fail(EP_ERR_INVALID, "ep_pool_host_target: row_offset = %lld", (long long)row_offset);
+  EP_ENTER_DEVICE(p->device);
+  char* host[11];
+  char* dev[11];
+  for (int k = 0; k < 11; ++k) {
+    const size_t need = ((size_t)row_offset + (size_t)p->B) * p->key_rowbytes[k];
+    if (key_off[k] > hb->set->bytes || need > hb->set->bytes - key_off[k])
+      return fail(EP_ERR_INVALID, "ep_pool_host_target: key %d needs %zu bytes at offset %zu of a %zu-byte block", k, need, key_off[k],
+                  hb->set->bytes);
+    // (the kernels choose their 16-byte stores by the ROW they start at: the arrays themselves must be 16-byte aligned)
+    if (key_off[k] % 16 != 0) return fail(EP_ERR_INVALID, "ep_pool_host_target: key %d at offset %zu is not 16-byte aligned", k, key_off[k]);
+    host[k] = (char*)block + key_off[k];
+  }
+  void* dv = nullptr;
+  if (hipHostGetDevicePointer(&dv, block, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(EP_ERR_HIP, "ep_pool_host_target: the block is not mapped into device %d", p->device);
+  }
+  for (int k = 0; k < 11; ++k) dev[k] = (char*)dv + key_off[k];
+  if (p->target_home) p->target_home->drop(p->target_block);  // a target nobody used is replaced
+  hb->set->hold(block);
+  p->target_home = hb->set;
+  p->target_block = block;
+  memcpy(p->target_host, host, sizeof(host));
+  memcpy(p->target_dev, dev, sizeof(dev));
+  p->target_row0 = row_offset;
+  p->target_pending = true;
   return EP_OK;
 }
 

@@ -88,6 +88,43 @@ inline int eager_dyn_max_env_id() {
   return v;
 }
 
+// ep_host_blocks behind two Python objects: the set, and one block out of it. A block goes back
+// to the set when the last numpy array over it (and the HostBlock object itself) has died.
+struct HostBlocksPy {
+  ep_host_blocks* hb = nullptr;
+  size_t bytes = 0;
+  explicit HostBlocksPy(size_t n) : bytes(n) { epy::check(ep_host_blocks_create(n, &hb)); }
+  ~HostBlocksPy() { ep_host_blocks_destroy(hb); }
+  HostBlocksPy(const HostBlocksPy&) = delete;
+};
+struct HostBlockPy {
+  std::shared_ptr<HostBlocksPy> home;
+  void* ptr = nullptr;
+  ~HostBlockPy() {
+    if (ptr) ep_host_blocks_give(home->hb, ptr);
+  }
+};
+inline std::shared_ptr<HostBlockPy> take_host_block(const std::shared_ptr<HostBlocksPy>& home) {
+  auto b = std::make_shared<HostBlockPy>();
+  b->home = home;
+  epy::check(ep_host_blocks_take(home->hb, &b->ptr));
+  return b;
+}
+// numpy array over `count` elements of the block at `offset`; the array keeps the block out of the set
+inline py::array host_block_array(const std::shared_ptr<HostBlockPy>& b, size_t offset, const std::vector<py::ssize_t>& shape,
+                                  const std::string& dtype) {
+  py::dtype dt(dtype);
+  size_t n = (size_t)dt.itemsize();
+  for (auto d : shape) {
+    if (d < 0) throw std::invalid_argument("negative dimension");
+    n *= (size_t)d;
+  }
+  if (offset > b->home->bytes || n > b->home->bytes - offset) throw std::invalid_argument("array does not fit into the block");
+  auto* keep = new std::shared_ptr<HostBlockPy>(b);
+  py::capsule cap(keep, [](void* p) { delete reinterpret_cast<std::shared_ptr<HostBlockPy>*>(p); });
+  return py::array(dt, shape, (char*)b->ptr + offset, cap);
+}
+
 struct DummyPool {
   DummySpec spec;
   ep_pool* pool = nullptr;
@@ -194,6 +231,32 @@ struct DummyPool {
     if (!deferred.empty()) throw std::runtime_error(deferred);
     return py::cast(ret);
   }
+
+  // Additive (ep_pool_host_target): the next batch this pool starts goes into `block`, slot key k
+  // at offsets[k]; `_recv_target` then receives it (no arrays are made here: the caller has its own
+  // over the block) and returns the number of rows.
+  void host_target(const std::shared_ptr<HostBlockPy>& block, const std::vector<size_t>& offsets, int64_t row_offset) {
+    if (offsets.size() != 11) throw std::invalid_argument("11 key offsets expected");
+    epy::check(ep_pool_host_target(pool, block->home->hb, block->ptr, offsets.data(), row_offset));
+  }
+  void host_target_cancel() { epy::check(ep_pool_host_target(pool, nullptr, nullptr, nullptr, 0)); }
+  int recv_target() {
+    ep_batch b;
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = ep_pool_recv(pool, EP_MEM_HOST, &b);
+    }
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    std::string deferred = batch_with_error ? ep_last_error() : "";
+    const bool in_target = b.owner == nullptr;
+    ep_batch_release(&b);
+    if (!deferred.empty()) throw std::runtime_error(deferred);
+    if (!in_target) throw std::runtime_error("_recv_target: the batch received was started before the target was set");
+    return b.num_rows;
+  }
+  py::object make_dyn_of(const py::array& players_env_id) { return make_dyn(players_env_id); }
 
   // Additive API: zero-copy device views, as (ptr, shape, typestr) descriptors in
   // _state_keys order (None for obs:dyn). See envpool_amd/interop.py.
@@ -491,6 +554,14 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
       .def_property_readonly_static("_config_keys", [](py::object) { return kConfigKeys; })
       .def_property_readonly_static("_default_config_values", [](py::object) { return default_config_values(); });
+  py::class_<HostBlocksPy, std::shared_ptr<HostBlocksPy>>(m, "HostBlocks")
+      .def(py::init<size_t>())
+      .def_readonly("bytes", &HostBlocksPy::bytes)
+      .def("take", [](const std::shared_ptr<HostBlocksPy>& self) { return take_host_block(self); });
+  py::class_<HostBlockPy, std::shared_ptr<HostBlockPy>>(m, "HostBlock")
+      .def_property_readonly("ptr", [](const HostBlockPy& b) { return reinterpret_cast<uintptr_t>(b.ptr); })
+      .def("array", [](const std::shared_ptr<HostBlockPy>& self, size_t offset, const std::vector<py::ssize_t>& shape,
+                       const std::string& dtype) { return host_block_array(self, offset, shape, dtype); });
   py::class_<DummyPool>(m, "_DummyEnvPool", py::metaclass(abc_meta))
       .def(py::init<const DummySpec&>())
       .def_readonly("_spec", &DummyPool::spec)
@@ -501,6 +572,10 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def_property_readonly_static("_action_keys", [](py::object) { return kActionKeys; })
       // additive (no reference counterpart)
       .def("_recv_device", &DummyPool::recv_device)
+      .def("_host_target", &DummyPool::host_target, py::arg("block"), py::arg("offsets"), py::arg("row_offset") = 0)
+      .def("_host_target_cancel", &DummyPool::host_target_cancel)
+      .def("_recv_target", &DummyPool::recv_target)
+      .def("_make_dyn", &DummyPool::make_dyn_of)
       .def("_recv_device_slot", &DummyPool::recv_device_slot)
       .def("_try_recv", &DummyPool::try_recv)
       .def("_try_recv_device", &DummyPool::try_recv_device)

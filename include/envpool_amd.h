@@ -21,6 +21,7 @@
 #ifndef ENVPOOL_AMD_H_
 #define ENVPOOL_AMD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -282,6 +283,36 @@ int ep_pool_recv_many(ep_pool* pool, int32_t mem, int32_t n, ep_batch* out);
 /* Frees the host block of a EP_MEM_HOST batch (the reference frees it when the
  * numpy capsule dies, py_envpool.h:42-46). No-op for device views. */
 int ep_batch_release(ep_batch* batch);
+
+/* Result memory that the CALLER lays out, for a front-end that puts several pools' batches into one
+ * array per key (python/sharded.py: K shard pools, one numpy array per key over all shards, no copy
+ * to stitch them). No counterpart in the reference: its one pool writes one StateBuffer
+ * (state_buffer.h:92-95); this is what keeps K pools looking like that to the host.
+ *
+ * ep_host_blocks is a recycling set of pinned blocks of `bytes` each, mapped into every device of the
+ * process. Blocks are reference-counted: ep_host_blocks_take hands one out held once,
+ * ep_host_blocks_give drops that hold, and a pool given the block as a target holds it until its
+ * batch is done with it - the memory goes back to the set (or is freed, after
+ * ep_host_blocks_destroy) when the last hold is dropped, never while a kernel may write it. */
+typedef struct ep_host_blocks ep_host_blocks;
+int ep_host_blocks_create(size_t bytes, ep_host_blocks** out);
+int ep_host_blocks_take(ep_host_blocks* blocks, void** block);
+int ep_host_blocks_give(ep_host_blocks* blocks, void* block);
+int ep_host_blocks_destroy(ep_host_blocks* blocks);
+
+/* The next batch that ep_pool_send / ep_pool_reset START on this pool is delivered into `block`:
+ * state key k (slot order: info:env_id, info:players.env_id, elapsed_step, done, reward, discount,
+ * step_type, trunc, obs:raw, info:players.done, info:players.id) is an array at block + key_off[k]
+ * (16-byte aligned), and row r of the batch goes to row row_offset + r of it - K pools given the
+ * same key_off and row_offset = 0, n, 2n, ... fill one array per key between them. Host-memory sends have their kernels write the block directly (as they
+ * write the pool's own block otherwise); batches written into the ring are copied there by
+ * ep_pool_recv(EP_MEM_HOST). That recv returns arrays pointing into the block with `owner` NULL.
+ * A batch received as device views after all is complete in its ring slot; what the block holds
+ * then is unspecified (its rows, if the kernels had written them there already). One target is pending at a time
+ * (a new one replaces it; hb = block = NULL cancels it). Refused with EP_ERR_INVALID when a key
+ * would not fit (rows row_offset .. row_offset + batch_size of the array at key_off[k], inside `bytes`), for a block that is not out of
+ * `blocks`, and for multi-player pools (their player rows have no fixed place). */
+int ep_pool_host_target(ep_pool* pool, ep_host_blocks* blocks, void* block, const size_t* key_off, int64_t row_offset);
 
 /* Fused lockstep loop: T consecutive sync-mode send+step rounds of ALL envs in
  * one kernel launch (the "persistent-kernel step loop" of the north star; the

@@ -558,3 +558,151 @@ def test_sharded_ygopro_pools_behind_one_front_end():
     ygopro.init_module(None, None)
     for e in engines.values():
       e.close()
+
+
+_SLOT_KEYS = [("<i4", 1, 0), ("<i4", 1, 1), ("<i4", 1, 2), ("|b1", 1, 3), ("<f4", 1, 4), ("<f4", 1, 5), ("<i4", 1, 6),
+              ("|b1", 1, 7), ("<i4", 10, 8), ("|b1", 1, 10), ("<i4", 1, 11)]   # (dtype, elements per row, state key)
+
+
+def _target_layout(rows):
+  offs, at = [], 0
+  for dt, elems, _ in _SLOT_KEYS:
+    offs.append(at)
+    at = (at + np.dtype(dt).itemsize * elems * rows + 255) // 256 * 256
+  return offs, at
+
+
+def _target_batch(blk, offs, rows, row0=0):
+  out = [None] * 12
+  for off, (dt, elems, k) in zip(offs, _SLOT_KEYS):
+    a = blk.array(off, (row0 + rows,) + ((elems,) if elems > 1 else ()), dt)
+    out[k] = a[row0:]
+  return out
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_host_target_delivers_a_batch_into_the_callers_block(direct, monkeypatch):
+  """ep_pool_host_target: the next batch a pool starts lands in the caller's pinned block, key by
+  key at the offsets given - written there by the step kernels (host-memory sends, direct = "1") or
+  copied there by recv (EP_DIRECT_HOST=0) - bit-exact against the oracle; two pools fill two row
+  ranges of ONE array per key (what python/sharded.py builds on). What is refused; a cancelled
+  target; a batch received as device views after all; a block is not recycled while an array over it
+  lives."""
+  import torch
+  from envpool_amd.dummy.dummy_envpool import HostBlocks, _DummyEnvPool, _DummyEnvSpec
+  from oracle.dummy_oracle import DummyOracle
+  monkeypatch.setenv("EP_DIRECT_HOST", direct)
+  n, seed = 5000, 11
+  keys = _DummyEnvSpec._config_keys
+  dflt = dict(zip(keys, _DummyEnvSpec._default_config_values))
+
+  def pool(**kw):
+    return _DummyEnvPool(_DummyEnvSpec(tuple(dict(dflt, **kw)[k] for k in keys)))
+
+  lo, hi = pool(num_envs=n, batch_size=n, seed=seed), pool(num_envs=n, batch_size=n, seed=seed, env_id_offset=n)
+  one = DummyOracle(num_envs=2 * n, seed=seed)
+  ids = np.arange(2 * n, dtype=np.int32)
+  offs, nbytes = _target_layout(2 * n)
+  hb = HostBlocks(nbytes)
+  rng = np.random.default_rng(0)
+  kept = []
+  for t in range(12):
+    blk = hb.take()
+    lo._host_target(blk, offs)
+    hi._host_target(blk, offs, n)
+    if t == 0:
+      lo._reset(ids[:n]); hi._reset(ids[n:]); one._reset(ids)
+    else:
+      pe = ids + (rng.random(2 * n) < 0.1).astype(np.int32)
+      a = dummy_action(ids, players_env_id=pe, value=float(t))
+      lo._send([x[:n] for x in a]); hi._send([x[n:] for x in a]); one._send(a)
+    assert lo._recv_target() == n and hi._recv_target() == n
+    got, want = _target_batch(blk, offs, 2 * n), one._recv()
+    assert_batches_equal(got, want, f"t={t}")
+    kept.append((got, want, blk.ptr))
+    del blk
+    if t >= 3:   # three batches stay alive: their blocks must not come round again
+      kept.pop(0)
+    assert len({p for *_, p in kept}) == len(kept)
+    for g, w, _ in kept:
+      assert_batches_equal(g, w, f"kept at t={t}")
+  ptrs_seen = {p for *_, p in kept}
+  kept.clear(); del got
+  assert hb.take().ptr in ptrs_seen                      # ... and do once nothing refers to them
+  # refusals (nothing is launched for any of them)
+  blk = hb.take()
+  with pytest.raises((RuntimeError, ValueError), match="needs .* bytes at offset"):
+    lo._host_target(blk, [o + nbytes for o in offs])
+  with pytest.raises((RuntimeError, ValueError), match="11 key offsets"):
+    lo._host_target(blk, offs[:10])
+  mp = pool(num_envs=64, batch_size=64, max_num_players=3, seed=seed)
+  with pytest.raises((RuntimeError, ValueError), match="max_num_players == 1"):
+    mp._host_target(blk, offs)
+  # a target that is cancelled, and one whose batch is received as device views
+  from envpool_amd import interop
+  p2, o2 = pool(num_envs=n, batch_size=n, seed=seed + 1), DummyOracle(num_envs=n, seed=seed + 1)
+  p2._reset(ids[:n]); o2._reset(ids[:n])
+  assert_batches_equal(p2._recv(), o2._recv(), "reset of the second pool")
+  sentinel = _target_batch(blk, offs, 2 * n)
+  for k in (0, 2, 8):
+    sentinel[k][...] = -7
+  a = dummy_action(ids[:n], value=3.0)
+  p2._host_target(blk, offs)
+  p2._host_target_cancel()
+  p2._send(a); o2._send(a)
+  assert_batches_equal(p2._recv(), o2._recv(), "after a cancelled target")
+  p2._host_target(blk, offs)
+  p2._send(a); o2._send(a)
+  descs, want = p2._recv_device()[0], o2._recv()
+  dev = torch.device("cuda", 0)
+  for k in (0, 2, 3, 4, 8):
+    assert interop.as_torch(descs[k], dev).cpu().numpy().tobytes() == np.asarray(want[k]).tobytes(), k
+  if direct == "0":   # (in direct mode the kernels had written the block before the batch was asked for as device views)
+    for k in (0, 2, 8):
+      assert (sentinel[k] == -7).all()
+  for q in (lo, hi, mp, p2):
+    q.close()
+
+
+def test_host_target_c_abi_refusals():
+  """The C entry points themselves: a block of another set, a block already given back, null
+  arguments; and a block given back while a pool still holds it as a target stays mapped until the
+  pool is done with it (the pool's batch is received into it afterwards)."""
+  import ctypes as C
+  from envpool_amd import capi
+  from tests.test_dummy_gpu_r2 import _pair
+  L = capi.lib()
+  n = 4096
+  g, o = _pair(num_envs=n, seed=5)
+  offs, nbytes = _target_layout(n)
+  c_offs = (C.c_size_t * 11)(*offs)
+  A, B = C.c_void_p(), C.c_void_p()
+  assert L.ep_host_blocks_create(nbytes + 256, C.byref(A)) == 0 and L.ep_host_blocks_create(nbytes + 256, C.byref(B)) == 0
+  none = C.c_void_p()
+  assert L.ep_host_blocks_create(0, C.byref(none)) == capi.EP_ERR_INVALID and not none.value
+  blk = C.c_void_p()
+  assert L.ep_host_blocks_take(A, C.byref(blk)) == 0 and blk.value
+  assert L.ep_pool_host_target(g.handle, B, blk, c_offs, 0) == capi.EP_ERR_INVALID
+  assert b"not a block that is out of this set" in L.ep_last_error()
+  assert L.ep_pool_host_target(g.handle, A, blk, None, 0) == capi.EP_ERR_INVALID
+  assert L.ep_pool_host_target(None, A, blk, c_offs, 0) == capi.EP_ERR_INVALID
+  assert L.ep_pool_host_target(g.handle, A, blk, c_offs, 100) == capi.EP_ERR_INVALID    # the last key would run past the block
+  assert L.ep_pool_host_target(g.handle, A, blk, c_offs, -1) == capi.EP_ERR_INVALID
+  odd = (C.c_size_t * 11)(*[o + 4 for o in offs])
+  assert L.ep_pool_host_target(g.handle, A, blk, odd, 0) == capi.EP_ERR_INVALID and b"16-byte aligned" in L.ep_last_error()
+  assert L.ep_host_blocks_give(B, blk) == capi.EP_ERR_INVALID
+  # target set, then the caller's own hold dropped: the pool's hold keeps the block
+  assert L.ep_pool_host_target(g.handle, A, blk, c_offs, 0) == 0, L.ep_last_error()
+  assert L.ep_host_blocks_give(A, blk) == 0
+  ids = np.arange(n, dtype=np.int32)
+  g._reset(ids); o._reset(ids)
+  b = capi.Batch()
+  assert L.ep_pool_recv(g.handle, capi.EP_MEM_HOST, C.byref(b)) == 0, L.ep_last_error()
+  assert b.owner is None and b.arrays[0].data == blk.value + offs[0] and b.arrays[8].data == blk.value + offs[8]
+  got, want = capi.batch_to_numpy(b), o._recv()
+  assert L.ep_batch_release(C.byref(b)) == 0
+  assert_batches_equal(got, want, "reset into a block the caller has let go of")
+  a = dummy_action(ids, value=2.0)
+  g._send(a); o._send(a)
+  assert_batches_equal(g._recv(), o._recv(), "the next batch goes into the pool's own block again")
+  assert L.ep_host_blocks_destroy(A) == 0 and L.ep_host_blocks_destroy(B) == 0

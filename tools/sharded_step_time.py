@@ -28,6 +28,9 @@ for n, b, k in ((8192, 4096, 1), (8192, 4096, 8)) if NUMPY else ():
         ts.append(time.perf_counter() - t0)
     print(f"async n={n} batch={b} shards={k}: recv + send {med(ts[50:]):8.1f} us per batch", flush=True)
 
+if os.environ.get('ONLY_NUMPY') == '1':
+    sys.exit(0)
+
 # the device path (round 3): CUDA tensors in, per-shard views of the rings out, nothing crosses PCIe;
 # a whole-pool step rings every shard's resident server and then waits for each
 import gc
