@@ -127,6 +127,31 @@ def main(rounds=int(os.environ.get("FUZZ_ROUNDS", "30"))):
       lambda: L.ep_terminated_many(1, one, one, one, (C.c_int64 * 1)(-4), -1, None),
       lambda: L.ep_terminated_many(1, one, (C.c_void_p * 1)(None), one, (C.c_int64 * 1)(4), -1, None),
     ]
+    # caller-laid-out result memory (ep_host_blocks_*, ep_pool_host_target): what is refused, and valid
+    # targets now and then - the batches that land in them are compared like any other
+    rowb = [4, 4, 4, 1, 4, 4, 4, 1, 40, 1, 4]
+    t_offs, at = [], 0
+    for b_ in rowb:
+      t_offs.append(at)
+      at = (at + b_ * (B + 16) + 255) // 256 * 256   # (room for a row offset of 16 in every key)
+    set_a, set_b, blk = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.ep_host_blocks_create(at + 4096, C.byref(set_a)) == 0 and L.ep_host_blocks_create(at + 4096, C.byref(set_b)) == 0
+    assert L.ep_host_blocks_take(set_a, C.byref(blk)) == 0
+    offs_ok = (C.c_size_t * 11)(*t_offs)
+    menu += [
+      lambda: L.ep_pool_host_target(h, set_b, blk, offs_ok, 0),                                  # a block of another set
+      lambda: L.ep_pool_host_target(h, set_a, blk, None, 0),
+      lambda: L.ep_pool_host_target(h, set_a, None, offs_ok, 0),
+      lambda: L.ep_pool_host_target(None, set_a, blk, offs_ok, 0),
+      lambda: L.ep_pool_host_target(h, set_a, blk, (C.c_size_t * 11)(*[o + 8 for o in t_offs]), 0),  # not 16-byte aligned
+      lambda: L.ep_pool_host_target(h, set_a, blk, offs_ok, -1),
+      lambda: L.ep_pool_host_target(h, set_a, blk, offs_ok, 4096 + 1),                            # past the end of the block
+      lambda: L.ep_pool_host_target(h, set_a, blk, (C.c_size_t * 11)(*[o + (1 << 40) for o in t_offs]), 0),
+      lambda: L.ep_host_blocks_give(set_b, blk),
+      lambda: L.ep_host_blocks_give(set_a, None),
+      lambda: L.ep_host_blocks_take(None, C.byref(C.c_void_p())),
+      lambda: L.ep_host_blocks_create(0, C.byref(C.c_void_p())),
+    ]
     if not sync:
       menu.append(lambda: call_rollout(1, 5, devp, full, [0] * 5))          # rollouts are for sync pools
     valid_step(first=True)
@@ -140,8 +165,18 @@ def main(rounds=int(os.environ.get("FUZZ_ROUNDS", "30"))):
         assert L.ep_pool_set_stream(h, None, 0) == 0 and L.ep_pool_poll_errors(h) == 0
         if it % 2:
           assert L.ep_pool_set_stream(h, None, 1) == 0
+      if it % 7 == 3:  # the next batch to START goes into the block (row offset 0 or 16), or the target is cancelled again
+        # a block of its own per target (several batches may be in flight), let go of at once: the pool's hold keeps it
+        b2 = C.c_void_p()
+        assert L.ep_host_blocks_take(set_a, C.byref(b2)) == 0
+        assert L.ep_pool_host_target(h, set_a, b2, offs_ok, int(rng.choice([0, 16]))) == 0, L.ep_last_error()
+        assert L.ep_host_blocks_give(set_a, b2) == 0
+        if it % 2:
+          assert L.ep_pool_host_target(h, None, None, None, 0) == 0
       valid_step()
     pool.close()
+    assert L.ep_host_blocks_give(set_a, blk) == 0
+    assert L.ep_host_blocks_destroy(set_a) == 0 and L.ep_host_blocks_destroy(set_b) == 0
     L.hipFree(dev)
     print(f"ok {r}: N={N} B={B} refused so far {refused}, env-steps compared {steps}", flush=True)
   print("dummy ABI fuzz passed:", refused, "calls refused,", steps, "env-steps compared with the oracle")
