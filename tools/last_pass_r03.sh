@@ -17,6 +17,7 @@ case "${PART:-1}" in
   SOAK_STREAM=1 SOAK_POOLS=120 SOAK_SEED=301 run dummy_soak_stream 500 python tools/dummy_soak.py
   SOAK_STREAM=1 SOAK_MIXED=1 SOAK_POOLS=100 SOAK_SEED=302 run dummy_soak_mixed 500 python tools/dummy_soak.py
   FUZZ_ROUNDS=60 FUZZ_SEED=303 run dummy_abi_fuzz 300 python tools/dummy_abi_fuzz.py
+  SOAK_SECONDS=90 SOAK_SEED=308 run sharded_soak 240 python tools/sharded_soak.py
   ;;
 2)
   SOAK_RECORDS=3000000 SOAK_SEED=304 run ygo_soak 700 python tools/ygo_soak.py
