@@ -50,7 +50,9 @@ examples/ygo_pool_loop: examples/ygo_pool_loop.c include/envpool_amd.h include/e
 examples/dummy_step_loop: examples/dummy_step_loop.c include/envpool_amd.h $(LIB)
 	gcc -O2 -std=c11 -Wall -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
 
-diag: tools/launch_floor tools/host_latency tools/doorbell_floor tools/server_ab
+diag: tools/launch_floor tools/host_latency tools/doorbell_floor tools/server_ab tools/pcie_write_ceiling
+tools/pcie_write_ceiling: tools/pcie_write_ceiling.cpp
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -o $@ $<
 tools/server_ab: tools/server_ab.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -Iinclude $< -Lenvpool_amd -lenvpool_amd -Wl,-rpath,'$$ORIGIN/../envpool_amd' -o $@
 tools/doorbell_floor: tools/doorbell_floor.cpp
@@ -85,7 +87,7 @@ build/sanitize_host: tools/sanitize_host.cpp tools/ygo_synth.c $(HIP_SRCS) $(HIP
 	  $(patsubst $(CSRC)/%.hip,build/san_%.o,$(HIP_SRCS)) build/ygo_synth_san.o -pthread
 
 clean:
-	rm -f $(LIB) $(PYMODS) tools/libygosynth.so examples/dummy_step_loop examples/ygo_pool_loop tools/launch_floor tools/host_latency tools/doorbell_floor tools/server_ab
+	rm -f $(LIB) $(PYMODS) tools/libygosynth.so examples/dummy_step_loop examples/ygo_pool_loop tools/launch_floor tools/host_latency tools/doorbell_floor tools/server_ab tools/pcie_write_ceiling
 	rm -rf build
 	$(MAKE) -C oracle clean
 
