@@ -706,3 +706,43 @@ def test_host_target_c_abi_refusals():
   g._send(a); o._send(a)
   assert_batches_equal(g._recv(), o._recv(), "the next batch goes into the pool's own block again")
   assert L.ep_host_blocks_destroy(A) == 0 and L.ep_host_blocks_destroy(B) == 0
+
+
+def test_stitch_parts_copies_every_key_of_every_part():
+  """stitch_parts (the sharded front-end's concatenate): parts of different row counts, a key without an
+  array, a non-contiguous input, sizes below and above the point where the copy is handed to the thread
+  crew; what does not fit is refused before anything is copied."""
+  from envpool_amd.dummy.dummy_envpool import HostBlocks, stitch_parts
+  rng = np.random.default_rng(3)
+  for rows_per_part in ([5, 1, 9], [3000, 4096, 1, 2500, 4096, 4096]):
+    shapes = [((), np.int32), ((160, 41), np.uint8), None, ((7,), np.float32), ((), np.bool_)]
+    total = sum(rows_per_part)
+    offs, at = [], 0
+    for sh in shapes:
+      offs.append(at)
+      if sh is not None:
+        at = (at + np.dtype(sh[1]).itemsize * int(np.prod(sh[0], dtype=np.int64)) * total + 255) // 256 * 256
+    hb = HostBlocks(at)
+    parts = []
+    for j, r in enumerate(rows_per_part):
+      part = []
+      for sh in shapes:
+        if sh is None:
+          part.append(None)
+          continue
+        a = rng.integers(0, 2 if sh[1] is np.bool_ else 100, size=(2 * r,) + sh[0]).astype(sh[1])
+        part.append(a[::2] if j % 2 else np.ascontiguousarray(a[::2]))    # odd parts: a strided view
+      parts.append(part)
+    blk = hb.take()
+    rows = stitch_parts(blk, offs, parts)
+    assert list(rows) == [total, total, 0, total, total]
+    for k, sh in enumerate(shapes):
+      if sh is None:
+        continue
+      got = blk.array(offs[k], (total,) + sh[0], np.dtype(sh[1]).str)
+      want = np.concatenate([p[k] for p in parts])
+      assert got.dtype == want.dtype and got.tobytes() == want.tobytes(), (rows_per_part, k)
+    with pytest.raises(ValueError, match="do not fit"):
+      stitch_parts(blk, [o + 256 for o in offs], parts + parts)
+    with pytest.raises(ValueError, match="one entry per key"):
+      stitch_parts(blk, offs, [parts[0][:3]])
