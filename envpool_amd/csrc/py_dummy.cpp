@@ -378,6 +378,46 @@ struct DummyPool {
   }
   py::object make_dyn_of(const py::array& players_env_id) { return make_dyn(players_env_id); }
 
+  // Additive: the poll of a front-end over several async pools (python/sharded.py). The next batch,
+  // if one is complete, is copied to rows row_offset... of the key arrays in `block` (slot-order
+  // offsets, as for _host_target) and its own block released at once; no numpy object is made per
+  // part. Returns the number of rows, or None when no batch is complete.
+  py::object try_recv_into(const std::shared_ptr<HostBlockPy>& block, const std::vector<size_t>& offsets, int64_t row_offset) {
+    static const int kStateToSlot[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, -1, 9, 10};
+    if (offsets.size() != 11 || row_offset < 0) throw std::invalid_argument("11 key offsets and a row offset >= 0 expected");
+    if (spec.cfg.max_num_players != 1) throw std::invalid_argument("_try_recv_into needs max_num_players == 1");
+    ep_batch b;
+    int rc;
+    std::string refused;
+    {
+      py::gil_scoped_release rel;
+      (void)ep_pool_set_recv_timeout(pool, 0);
+      rc = ep_pool_recv(pool, EP_MEM_HOST, &b);
+      (void)ep_pool_set_recv_timeout(pool, timeout_ms);
+      if (rc == EP_OK || rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV) {
+        for (int k = 0; k < b.num_keys && refused.empty(); ++k) {
+          const int sk = kStateToSlot[k];
+          if (sk < 0) continue;
+          const ep_array& a = b.arrays[k];
+          size_t rowb = a.dtype == EP_BOOL || a.dtype == EP_U8 ? 1 : a.dtype == EP_F64 ? 8 : 4;
+          for (int d = 1; d < a.ndim; ++d) rowb *= (size_t)a.shape[d];
+          const size_t at = offsets[sk] + (size_t)row_offset * rowb, n = (size_t)a.shape[0] * rowb;
+          if (at > block->home->bytes || n > block->home->bytes - at) refused = "_try_recv_into: the batch does not fit into the block";
+          else if (n) memcpy((char*)block->ptr + at, a.data, n);
+        }
+      }
+    }
+    if (rc == EP_ERR_WOULD_BLOCK) return py::none();
+    const bool batch_with_error = rc == EP_ERR_ACTION_CHECK || rc == EP_ERR_DUP_ENV;
+    if (rc != EP_OK && !batch_with_error) epy::check(rc);
+    std::string deferred = batch_with_error ? ep_last_error() : "";
+    const int rows = b.num_rows;
+    ep_batch_release(&b);
+    if (!refused.empty()) throw std::invalid_argument(refused);
+    if (!deferred.empty()) throw std::runtime_error(deferred);
+    return py::int_(rows);
+  }
+
   // Additive API: zero-copy device views, as (ptr, shape, typestr) descriptors in
   // _state_keys order (None for obs:dyn). See envpool_amd/interop.py.
   py::tuple recv_device() { return recv_device_impl(false).cast<py::tuple>(); }
@@ -697,6 +737,7 @@ PYBIND11_MODULE(dummy_envpool, m) {
       .def("_host_target_cancel", &DummyPool::host_target_cancel)
       .def("_recv_target", &DummyPool::recv_target)
       .def("_make_dyn", &DummyPool::make_dyn_of)
+      .def("_try_recv_into", &DummyPool::try_recv_into, py::arg("block"), py::arg("offsets"), py::arg("row_offset"))
       .def("_recv_device_slot", &DummyPool::recv_device_slot)
       .def("_try_recv", &DummyPool::try_recv)
       .def("_try_recv_device", &DummyPool::try_recv_device)

@@ -127,6 +127,7 @@ class ShardedRawPool(metaclass=ABCMeta):
     self._pending = deque()  # sync mode: per outstanding send, the positions of each shard's envs
     self._tgt = None         # (HostBlocks, key offsets, row bytes, dtypes, row shapes): see _setup_target
     self._stitch = None      # (HostBlocks class, stitch function): see _setup_stitch
+    self._inc = None         # async recv in progress: [block, parts copied into it so far]
     self._next = 0                         # async recv: where the rotation over the shards stands
     self._timeout_ms = -1
     self._last_owners: List[int] = []
@@ -170,6 +171,18 @@ class ShardedRawPool(metaclass=ABCMeta):
       # out: an async actor loop sends back exactly that): slices as well
       b = np.searchsorted(owner, np.arange(self._K + 1), side="left")
       return [slice(int(b[r]), int(b[r + 1])) for r in range(self._K)]
+    if not self._sync and n:
+      # an async actor loop sends back the ids of the batch it was handed: whole shard batches, in
+      # the order the shards were ready - a few runs of one owner each. (Only for async pools: a sync
+      # batch's rows come back in shard order, which is the sent order only if the runs ascend.)
+      cuts = np.flatnonzero(owner[1:] != owner[:-1]) + 1
+      if cuts.size < 4 * self._K:
+        edges = [0] + cuts.tolist() + [n]
+        runs: List[List] = [[] for _ in range(self._K)]
+        for a, b in zip(edges[:-1], edges[1:]):
+          runs[int(owner[a])].append((a, b))
+        return [slice(0, 0) if not rs else slice(*rs[0]) if len(rs) == 1 else np.concatenate([np.arange(a, b) for a, b in rs])
+                for rs in runs]
     return [np.nonzero(owner == r)[0] for r in range(self._K)]
 
   @staticmethod
@@ -183,11 +196,12 @@ class ShardedRawPool(metaclass=ABCMeta):
     batch whose ids ascend then needs no copy to be stitched (4.6 MB of them per step of 65 536 envs:
     127 us of a 314 us step over 4 shards)."""
     offs, rowb, at = [], [], 0
+    cap = self._N if self._sync else self._B  # rows of a node-wide batch
     for dt, tail, _ in slot_keys:
       nb = np.dtype(dt).itemsize * int(np.prod(tail, dtype=np.int64))
       offs.append(at)
       rowb.append(nb)
-      at = (at + nb * self._N + 255) // 256 * 256
+      at = (at + nb * cap + 255) // 256 * 256
     self._tgt = (make_blocks(max(at, 256)), offs, rowb, list(slot_keys))
 
   def _fan_out(self, env_id: np.ndarray, per_shard: Callable) -> None:
@@ -330,6 +344,30 @@ class ShardedRawPool(metaclass=ABCMeta):
   # ---- stitch ----------------------------------------------------------------------------
   def _recv(self) -> List:
     if not self._sync:
+      if self._tgt is not None and self._P == 1 and all(hasattr(s, "_try_recv_into") for s in self._shards):
+        # every part is copied to its rows of ONE block by the shard's poll itself (no numpy object per
+        # part, the shard's own block free again at once): part j of the batch -> rows j * batch_size / K
+        blocks, offs, _, keys = self._tgt
+        if self._inc is None:
+          self._inc = [blocks.take(), 0]
+        inc = self._inc
+
+        def take(r):
+          rows = self._shards[r]._try_recv_into(inc[0], offs, inc[1] * self._b_local)
+          if rows is None:
+            return None
+          if rows != self._b_local:
+            raise RuntimeError(f"shard {r} handed out {rows} rows, not its batch of {self._b_local}")
+          inc[1] += 1
+          return rows
+        parts = self._gather_parts(take)
+        self._inc = None
+        out = [None] * self._nkeys
+        for off, (dt, tail, k) in zip(offs, keys):
+          out[k] = inc[0].array(off, (len(parts) * self._b_local,) + tuple(tail), dt)
+        if self._dyn is not None:
+          out[self._dyn] = self._shards[-1]._make_dyn(out[1])
+        return out
       if all(hasattr(s, "_try_recv") for s in self._shards):
         parts = self._gather_parts(lambda r: self._shards[r]._try_recv())
       else:  # shard pools that cannot be polled: one batch of each, in turn
@@ -851,7 +889,7 @@ def _build_dummy_classes():
       if os.environ.get("EP_SHARD_STITCH", "1") != "0":
         from ..dummy.dummy_envpool import HostBlocks, stitch_parts
         self._setup_stitch(HostBlocks, stitch_parts)
-      if self._sync and os.environ.get("EP_SHARD_TARGET", "1") != "0":
+      if self._P == 1 and os.environ.get("EP_SHARD_TARGET", "1") != "0":
         from ..dummy.dummy_envpool import HostBlocks
         S = cfg["state_num"]
         sk = list(self._state_keys).index

@@ -487,3 +487,41 @@ def test_kept_results_are_handed_out_with_new_dicts():
   assert "mine" not in kept[4] and "mine" not in kept[4]["players"]
   nt = ("not", "a", "result")
   assert fresh(list(nt)) == list(nt)
+
+
+def test_sharded_async_send_routes_runs_of_one_owner():
+  """An async actor loop sends back the ids it was handed: whole shard batches in the order the shards
+  were ready. `_positions` turns runs of one owner into slices (views downstream, no gather), a shard
+  with two runs into one index array, and falls back to the per-shard search for scattered ids; a sync
+  pool keeps the order-preserving rule (its rows come back in shard order). End to end: every batch
+  sent back at once with its own ids, against one big pool, as sets keyed by info:env_id."""
+  from oracle.dummy_oracle import DummyOracle
+  from envpool_amd.python.sharded import ShardedRawPool
+  from tests.util import dummy_action
+  K, n, b, seed = 4, 16, 4, 3
+  sh = ShardedRawPool(K * n, K * b, 1, 10, K, lambda *a: _OracleShard(*a, seed=seed))
+  for ids in ([40, 41, 42, 43, 3, 2, 1, 0, 20, 21, 60, 63],            # runs of shards 2, 0, 1, 3
+              [40, 41, 3, 2, 44, 45, 20, 21],                            # shard 2 in two runs
+              list(np.random.default_rng(0).permutation(64)[:40])):    # scattered: the search per shard
+    ids = np.asarray(ids, np.int32)
+    pos = sh._positions(ids)
+    assert len(pos) == K
+    for r, p in enumerate(pos):
+      sel = ids[p]
+      assert sel.tolist() == [e for e in ids.tolist() if e // n == r], (ids.tolist(), r)
+  assert isinstance(sh._positions(np.asarray([40, 41, 3, 2], np.int32))[2], slice)
+  sync = ShardedRawPool(K * n, 0, 1, 10, K, lambda *a: _OracleShard(*a, seed=seed))
+  assert not all(isinstance(p, slice) for p in sync._positions(np.asarray([40, 41, 3, 2], np.int32)))
+  one = DummyOracle(num_envs=K * n, batch_size=K * b, seed=seed)
+  all_ids = np.arange(K * n, dtype=np.int32)
+  sh._reset(all_ids); one._reset(all_ids)
+  got, want = {}, {}
+  for it in range(40):
+    g, w = sh._recv(), one._recv()
+    _rows_by_env(g, got); _rows_by_env(w, want)
+    sh._send(dummy_action(np.asarray(g[0]))); one._send(dummy_action(np.asarray(w[0])))
+  common = set(got) & set(want)
+  assert len(common) == K * n
+  for e in common:  # (the two pools hand the envs out in different batches: compare the steps both have reported)
+    m = min(len(got[e]), len(want[e]))
+    assert m >= 1 and got[e][:m] == want[e][:m], e
