@@ -208,7 +208,7 @@ __device__ __forceinline__ void store_raw_tile(int32_t* __restrict__ gdst, const
 
 template <int S_CT>
 __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_base, int nvalid,
-                                               int S_rt, const Stage& st, int tid) {
+                                               int S_rt, const Stage& st, int tid, bool skip_const = false) {
   // Four waves share the eleven key tiles; the branch is wave-uniform.
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -235,8 +235,9 @@ __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_b
     put4(sp.discount, st.discount);
     put1(sp.pdone, st.done);  // dummy_envpool.h:149/:201 players.done = IsDone()
   }
-  // constant-valued keys and obs:raw are spread over all four waves
-  {
+  // constant-valued keys and obs:raw are spread over all four waves. (skip_const: the rows go to host
+  // memory over PCIe and the host has zeroed these two arrays itself: 8 of 72 bytes per env less to cross.)
+  if (!skip_const) {
     // reward[0] = float(-0) = +0.0f, players.id[0] = 0 (dummy_envpool.h:148,152 / :200,204)
     const uint4 z = make_uint4(0, 0, 0, 0);
     uint32_t* rw = reinterpret_cast<uint32_t*>(sp.reward) + row_base;
@@ -281,6 +282,7 @@ struct StepArgs {
   int32_t force_reset;
   int32_t la_bit0;
   uint8_t* term;  // [B] or null: gymnasium's terminated = done & ~trunc of each row, beside the slot (ep_pool_terminated_of)
+  int32_t skip_const;  // 1: reward / info:players.id (always zero) are written by the host (rows that go to host memory)
 };
 
 // DEV: the device-memory step (not a reset, list_action rows on the device, duplicate stamps on):
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
     if (a.term) a.term[(int64_t)a.row0 + i] = (uint8_t)(o.done & (o.trunc ^ 1));  // (64 lanes, 64 consecutive bytes)
   }
   __syncthreads();
-  write_tiles_sp<S_CT>(a.slot, (int64_t)a.row0 + (int64_t)blockIdx.x * kBlock, blk_valid, a.pc.S, st, tid);
+  write_tiles_sp<S_CT>(a.slot, (int64_t)a.row0 + (int64_t)blockIdx.x * kBlock, blk_valid, a.pc.S, st, tid, !DEV && a.skip_const);
   if (check_stamp && old_stamp == a.stamp_val) a.err->dup_env = 1u;  // this launch had stepped the env already
 }
 

@@ -110,6 +110,7 @@ struct ep_pool {
   int N = 0, B = 0, P = 0, S = 0, Q = 0;
   bool is_sync = false;
   bool direct_host = true;  // EP_DIRECT_HOST=0: always stage host batches through the copy engine
+  bool host_const = true;   // EP_HOST_CONST=0: the kernels write the all-zero arrays of a host-memory batch too
   int direct_min_rows = 1;  // EP_DIRECT_MIN_ROWS (4096 until round 2: the staged copies cost a small pool 24 us per step)
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -625,7 +626,7 @@ int server_start(ep_pool* p, const void* const* arrs) {
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
               int slot, int err_w, int row0, bool force_reset, bool check_dup, const LaunchEvents& le,
               char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr, int la_bit0 = 0,
-              char* const* ext_dev = nullptr) {
+              char* const* ext_dev = nullptr, bool host_const = false) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
@@ -644,6 +645,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
   a.term = (out_base || ext_dev) ? nullptr : p->d_term + (size_t)slot * p->term_stride;
+  a.skip_const = host_const ? 1 : 0;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
   const bool dev = !force_reset && d_la && a.stamp && !p->force_generic;  // (see dummy_step_sp)
   if (p->S == 10 && dev)
@@ -736,10 +738,14 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     LaunchEvents le;
     if ((rc = begin_launch(p, &le, st))) break;
     const bool ext_direct = sh.ext && sh.host_blk;
+    // rows that the kernel writes over PCIe: the two arrays that are zero for every env (reward,
+    // info:players.id: dummy_envpool.h:148,152 / :200,204) are zeroed HERE instead, below, while the
+    // kernel runs - 8 of the 72 bytes per env do not cross the link, which is what bounds this path
+    const bool host_const = p->host_const && sh.host_blk != nullptr;
     rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
                    d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0 + (ext_direct ? (int)sh.ext_row0 : 0), force_reset,
                    !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0,
-                   ext_direct ? sh.ext_dev : nullptr);
+                   ext_direct ? sh.ext_dev : nullptr, host_const);
     if (rc != EP_OK) { abandon_launch(p, le); break; }
     sh.term_ok = (sh.has_work ? sh.term_ok : true) && out_base == nullptr && !ext_direct;
     sh.alloc_count += cnt;
@@ -748,6 +754,13 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     sh.has_work = true;
     sh.launch_id = ++p->launch_seq;
     end_launch(p, le, sh.launch_id);
+    if (host_const) {
+      const size_t r = (size_t)row0 + (sh.ext ? (size_t)sh.ext_row0 : 0);
+      char* rw = sh.ext ? sh.ext_host[4] : (char*)sh.host_blk + p->key_off[4];
+      char* pi = sh.ext ? sh.ext_host[10] : (char*)sh.host_blk + p->key_off[10];
+      memset(rw + 4 * r, 0, 4 * (size_t)cnt);
+      memset(pi + 4 * r, 0, 4 * (size_t)cnt);
+    }
     p->alloc_count += cnt;
     i0 += cnt;
   }
@@ -969,6 +982,7 @@ int ep_dummy_pool_create(const ep_dummy_config* cfg, ep_pool** out) {
   if (const char* fo = getenv("EP_MP_FOLD")) p->mp_fold = fo[0] == '1';
   if (const char* dh = getenv("EP_DIRECT_HOST")) p->direct_host = dh[0] != '0';
   if (const char* dm = getenv("EP_DIRECT_MIN_ROWS")) p->direct_min_rows = atoi(dm);
+  if (const char* hc = getenv("EP_HOST_CONST")) p->host_const = hc[0] != '0';
   if (const char* rv = getenv("EP_ROLLOUT_VARIANT")) p->rollout_variant = atoi(rv);
   EP_ENTER_DEVICE(p->device);
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
