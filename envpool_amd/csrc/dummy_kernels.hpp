@@ -208,7 +208,7 @@ __device__ __forceinline__ void store_raw_tile(int32_t* __restrict__ gdst, const
 
 template <int S_CT>
 __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_base, int nvalid,
-                                               int S_rt, const Stage& st, int tid, bool skip_const = false) {
+                                               int S_rt, const Stage& st, int tid, int host_keys = 0) {
   // Four waves share the eleven key tiles; the branch is wave-uniform.
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -224,8 +224,10 @@ __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_b
     else for (int t = lane; t < nvalid; t += 64) g[row_base + t] = l[t];
   };
   if (wave == 0) {
-    put4(sp.env_id, st.env_id);
-    put4(sp.penv, st.env_id);  // env.h:210-213: info:players.env_id[0] = env_id
+    if (!(host_keys & 2)) {  // (host_keys bit 1: the sender copies the ids it sent into these two itself)
+      put4(sp.env_id, st.env_id);
+      put4(sp.penv, st.env_id);  // env.h:210-213: info:players.env_id[0] = env_id
+    }
     put1(sp.done, st.done);
   } else if (wave == 1) {
     put4(sp.elapsed, st.elapsed);
@@ -235,9 +237,9 @@ __device__ __forceinline__ void write_tiles_sp(const SlotPtrs& sp, int64_t row_b
     put4(sp.discount, st.discount);
     put1(sp.pdone, st.done);  // dummy_envpool.h:149/:201 players.done = IsDone()
   }
-  // constant-valued keys and obs:raw are spread over all four waves. (skip_const: the rows go to host
-  // memory over PCIe and the host has zeroed these two arrays itself: 8 of 72 bytes per env less to cross.)
-  if (!skip_const) {
+  // constant-valued keys and obs:raw are spread over all four waves. (host_keys bit 0: the rows go to host
+  // memory over PCIe and the host zeroes these two arrays itself: 8 of 72 bytes per env less to cross.)
+  if (!(host_keys & 1)) {
     // reward[0] = float(-0) = +0.0f, players.id[0] = 0 (dummy_envpool.h:148,152 / :200,204)
     const uint4 z = make_uint4(0, 0, 0, 0);
     uint32_t* rw = reinterpret_cast<uint32_t*>(sp.reward) + row_base;
@@ -282,7 +284,8 @@ struct StepArgs {
   int32_t force_reset;
   int32_t la_bit0;
   uint8_t* term;  // [B] or null: gymnasium's terminated = done & ~trunc of each row, beside the slot (ep_pool_terminated_of)
-  int32_t skip_const;  // 1: reward / info:players.id (always zero) are written by the host (rows that go to host memory)
+  int32_t host_keys;  // rows that go to host memory: bit 0 - reward / info:players.id (always zero), bit 1 - info:env_id /
+                      // info:players.env_id (the ids that were sent) are written by the sending thread, not over PCIe
 };
 
 // DEV: the device-memory step (not a reset, list_action rows on the device, duplicate stamps on):
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void dummy_step_sp(StepArgs a) {
     if (a.term) a.term[(int64_t)a.row0 + i] = (uint8_t)(o.done & (o.trunc ^ 1));  // (64 lanes, 64 consecutive bytes)
   }
   __syncthreads();
-  write_tiles_sp<S_CT>(a.slot, (int64_t)a.row0 + (int64_t)blockIdx.x * kBlock, blk_valid, a.pc.S, st, tid, !DEV && a.skip_const);
+  write_tiles_sp<S_CT>(a.slot, (int64_t)a.row0 + (int64_t)blockIdx.x * kBlock, blk_valid, a.pc.S, st, tid, DEV ? 0 : a.host_keys);
   if (check_stamp && old_stamp == a.stamp_val) a.err->dup_env = 1u;  // this launch had stepped the env already
 }
 

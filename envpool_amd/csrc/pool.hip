@@ -626,7 +626,7 @@ int server_start(ep_pool* p, const void* const* arrs) {
 int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la, int n,
               int slot, int err_w, int row0, bool force_reset, bool check_dup, const LaunchEvents& le,
               char* out_base = nullptr, hipStream_t st = nullptr, const uint32_t* la_ok = nullptr, int la_bit0 = 0,
-              char* const* ext_dev = nullptr, bool host_const = false) {
+              char* const* ext_dev = nullptr, int host_keys = 0) {
   if (!st) st = p->stream;
   epk::StepArgs a;
   a.env_id = d_env_id;
@@ -645,7 +645,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
   a.row0 = row0;
   a.force_reset = force_reset ? 1 : 0;
   a.term = (out_base || ext_dev) ? nullptr : p->d_term + (size_t)slot * p->term_stride;
-  a.skip_const = host_const ? 1 : 0;
+  a.host_keys = host_keys;
   dim3 grid((n + epk::kBlock - 1) / epk::kBlock), block(epk::kBlock);
   const bool dev = !force_reset && d_la && a.stamp && !p->force_generic;  // (see dummy_step_sp)
   if (p->S == 10 && dev)
@@ -674,7 +674,7 @@ int launch_sp(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const 
 int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, const double* d_la,
                    int n, int np_rows, bool force_reset, const std::vector<int>* cuts, bool host_checked,
                    int row_base = 0, bool host_mode = false, hipStream_t st = nullptr,
-                   const uint32_t* la_ok = nullptr, int la_bit_base = 0) {
+                   const uint32_t* la_ok = nullptr, int la_bit_base = 0, const int32_t* h_ids = nullptr) {
   if (n == 0) return EP_OK;
   if (p->poisoned) return fail(EP_ERR_HIP, "the pool is in a failed state after an earlier launch error");
   const uint64_t B = (uint64_t)p->B;
@@ -741,11 +741,13 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     // rows that the kernel writes over PCIe: the two arrays that are zero for every env (reward,
     // info:players.id: dummy_envpool.h:148,152 / :200,204) are zeroed HERE instead, below, while the
     // kernel runs - 8 of the 72 bytes per env do not cross the link, which is what bounds this path
-    const bool host_const = p->host_const && sh.host_blk != nullptr;
+    // (and the two that hold the ids that were sent - validated before they got here - are copied from
+    // the caller's array: 16 of 72 bytes in all)
+    const int host_keys = (p->host_const && sh.host_blk != nullptr) ? (h_ids ? 3 : 1) : 0;
     rc = launch_sp(p, d_env_id + i0, d_penv ? d_penv + i0 : nullptr,
                    d_la ? d_la + (size_t)i0 * 6 : nullptr, cnt, slot, err_index(p, bi), row0 + (ext_direct ? (int)sh.ext_row0 : 0), force_reset,
                    !host_checked && !force_reset, le, out_base, st, la_ok, la_bit_base + i0,
-                   ext_direct ? sh.ext_dev : nullptr, host_const);
+                   ext_direct ? sh.ext_dev : nullptr, host_keys);
     if (rc != EP_OK) { abandon_launch(p, le); break; }
     sh.term_ok = (sh.has_work ? sh.term_ok : true) && out_base == nullptr && !ext_direct;
     sh.alloc_count += cnt;
@@ -754,12 +756,15 @@ int enqueue_slices(ep_pool* p, const int32_t* d_env_id, const int32_t* d_penv, c
     sh.has_work = true;
     sh.launch_id = ++p->launch_seq;
     end_launch(p, le, sh.launch_id);
-    if (host_const) {
+    if (host_keys) {
       const size_t r = (size_t)row0 + (sh.ext ? (size_t)sh.ext_row0 : 0);
-      char* rw = sh.ext ? sh.ext_host[4] : (char*)sh.host_blk + p->key_off[4];
-      char* pi = sh.ext ? sh.ext_host[10] : (char*)sh.host_blk + p->key_off[10];
-      memset(rw + 4 * r, 0, 4 * (size_t)cnt);
-      memset(pi + 4 * r, 0, 4 * (size_t)cnt);
+      auto key = [&](int k) { return (sh.ext ? sh.ext_host[k] : (char*)sh.host_blk + p->key_off[k]) + 4 * r; };
+      memset(key(4), 0, 4 * (size_t)cnt);
+      memset(key(10), 0, 4 * (size_t)cnt);
+      if (host_keys & 2) {
+        memcpy(key(0), h_ids + i0, 4 * (size_t)cnt);
+        memcpy(key(1), h_ids + i0, 4 * (size_t)cnt);
+      }
     }
     p->alloc_count += cnt;
     i0 += cnt;
@@ -1223,7 +1228,8 @@ int ep_pool_reset(ep_pool* p, const int32_t* env_ids, int32_t n, int32_t mem) {
   void* stage_dev = nullptr;
   if (p->direct_host && n >= p->direct_min_rows && hipHostGetDevicePointer(&stage_dev, h, 0) == hipSuccess) {
     // host mode (see ep_pool_send): the kernel reads the ids from the pinned staging area itself
-    rc = enqueue_slices(p, (const int32_t*)stage_dev, nullptr, nullptr, n, 0, true, nullptr, true, 0, /*host_mode=*/true);
+    rc = enqueue_slices(p, (const int32_t*)stage_dev, nullptr, nullptr, n, 0, true, nullptr, true, 0, /*host_mode=*/true, nullptr,
+                        nullptr, 0, env_ids);
   } else {
     if ((rc = stage_commit(p, a, 4 * (size_t)n))) return rc;
     rc = enqueue_slices(p, (const int32_t*)(p->d_stage + (size_t)a * p->stage_bytes), nullptr, nullptr, n, 0, true, nullptr, true);
@@ -1301,7 +1307,7 @@ int ep_pool_send(ep_pool* p, int32_t n_arrays, const void* const* arrays, const 
         // the Step branch - is still decided by the kernel, which knows the env's state)
         la_lanes_equal((const double*)arrays[2] + 6 * (size_t)c0, cnt, (uint32_t*)(h + o2) + (c0 >> 5));
         rc = enqueue_slices(p, (const int32_t*)(sd + o0) + c0, (const int32_t*)(sd + o1) + c0, nullptr, cnt, cnt, false,
-                            cuts, true, c0, /*host_mode=*/true, nullptr, (const uint32_t*)(sd + o2), c0);
+                            cuts, true, c0, /*host_mode=*/true, nullptr, (const uint32_t*)(sd + o2), c0, (const int32_t*)arrays[0] + c0);
       }
       int rc2 = stage_release(p, a);
       return rc ? rc : rc2;
