@@ -19,6 +19,11 @@ them; there is no device exchange.
   are polled in rotation (`_try_recv`); when none is ready the call naps and polls again (it never
   sits on one shard while another may complete first). Rows come part by part, arrival order inside a
   part; like the reference's arrival order this is to be compared as a set keyed by `info:env_id`.
+* host arrays without a stitch: an ascending sync send has every shard's kernels write their rows
+  of ONE pinned array per key (`ep_pool_host_target`, a recycled reference-counted block); async
+  Dummy shards copy their part into the node-wide block at the poll (`_try_recv_into`); whatever is
+  still stitched (permuted ids scatter by index; YGOPro and multi-player parts) is one threaded copy
+  into such a block (`stitch_parts`) instead of a numpy concatenate per key.
 * device path (additive): `reset_torch / recv_torch / send_torch / step_torch` keep every byte on
   the shards' GPUs. A result is a `ShardedResult`: one ordinary result per shard (or per received
   part), each on its own device, in shard order = ascending env ids; `.cat(device)` stitches them
