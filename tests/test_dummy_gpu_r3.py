@@ -481,3 +481,41 @@ def test_entry_points_leave_the_current_device_alone():
   g.close()
   assert L.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
   assert torch.cuda.current_device() == before
+
+
+@pytest.mark.parametrize("host_const", ["1", "0"])
+def test_host_memory_batches_with_and_without_host_written_arrays(host_const, monkeypatch):
+  """A batch whose rows go to host memory has four of its eleven arrays written by the sending thread
+  (reward and info:players.id: zero for every env; info:env_id / info:players.env_id: the ids that were
+  sent) instead of by the kernel over PCIe (EP_HOST_CONST=1, the default; =0: the kernel writes all
+  eleven). Both against the oracle: whole-pool and partial sends, an env named twice in one send (split
+  launches), a reset of a subset, a device-memory send into the same kind of batch, an async pool whose
+  sends straddle batches."""
+  monkeypatch.setenv("EP_HOST_CONST", host_const)
+  rng = np.random.default_rng(8)
+  for kw in (dict(num_envs=40000, seed=5), dict(num_envs=5000, batch_size=1300, seed=6)):
+    g, o = _pair(**kw)
+    n = kw["num_envs"]
+    B = kw.get("batch_size", 0) or n
+    ids = np.arange(n, dtype=np.int32)
+    g._reset(ids); o._reset(ids)
+    for it in range(14 if B == n else 40):   # (every batch received is sent back: one is always there)
+      got, want = g._recv(), o._recv()
+      assert_batches_equal(got, want, f"{kw} it={it}")
+      back = np.asarray(got[0])
+      if B == n:
+        if it % 4 == 1:
+          back = rng.permutation(back)
+        elif it % 4 == 2:
+          back = np.concatenate([back[:100], back[:3], back[100:n - 3]])   # three envs named twice, three left out
+        elif it % 4 == 3:
+          sub = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)
+          g._reset(sub); o._reset(sub)
+          assert_batches_equal(g._recv(), o._recv(), f"{kw} it={it} subset reset")
+      pe = back + (rng.random(back.size) < 0.1).astype(np.int32)
+      a = dummy_action(back, players_env_id=pe, value=float(it))
+      if it % 5 == 4 and B == n and len(set(back.tolist())) == back.size:
+        g._send_via_device(a)
+      else:
+        g._send(a)
+      o._send(a)
