@@ -124,7 +124,8 @@ def main():
   # two ranks on one GPU, which exercises the fall-back of the stat exchange.
   rehearse = os.environ.get("EP_BENCH_REHEARSE") in ("1", "2")
   rehearse_real_init = os.environ.get("EP_BENCH_REHEARSE") == "2"
-  dev_index = 0 if rehearse else local_rank
+  # (a launcher that shows every rank only its own GPU leaves one visible device: index 0 there)
+  dev_index = 0 if rehearse else local_rank % max(1, torch.cuda.device_count())
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
   # EP_BENCH_FORCE_DIST=1: take the N>1 code path (process group, RCCL stat exchange on a side
